@@ -1,0 +1,12 @@
+"""MI355X-native Gaussian-splat majority-vote labeler + rasterizer (host side of libgsx.so).
+
+The directory name starts with a digit, so import it with
+    importlib.import_module("3d_gaussian_splatting_project_amd")
+"""
+from . import _lib
+from ._lib import Camera, GsxError, build, lib
+from . import dist, scene
+from .labeler import Context, assign_labels_from_maps, load_cameras, project_gaussian
+
+__all__ = ["Camera", "Context", "GsxError", "assign_labels_from_maps", "build", "dist", "lib", "load_cameras",
+           "project_gaussian", "scene"]

@@ -1,0 +1,302 @@
+// libgsx.so — C ABI entry points (include/gsx.h): context, scene upload, profiling, dispatch.
+// No exception crosses the boundary; every entry returns a gsx_status.
+#include <cstring>
+#include <new>
+
+#include "gsx_ctx.hpp"
+
+namespace gsx {
+
+static thread_local std::string g_err;
+
+void set_global_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int fail(Ctx* c, int code, const char* fmt, ...) {
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_err = buf;
+    return code;
+}
+
+ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
+    if (!c->prof_on) return;
+    int id = -1;
+    for (size_t i = 0; i < c->prof_names.size(); ++i)
+        if (c->prof_names[i] == name) id = (int)i;
+    if (id < 0) {
+        c->prof_names.emplace_back(name);
+        id = (int)c->prof_names.size() - 1;
+    }
+    auto get = [&](hipEvent_t& e) {
+        if (!c->event_pool.empty()) {
+            e = c->event_pool.back();
+            c->event_pool.pop_back();
+            return true;
+        }
+        return hipEventCreate(&e) == hipSuccess;
+    };
+    if (!get(ev.start) || !get(ev.stop)) return;
+    ev.name_id = id;
+    active = hipEventRecord(ev.start, c->stream) == hipSuccess;
+}
+
+ProfScope::~ProfScope() {
+    if (!active) return;
+    (void)hipEventRecord(ev.stop, c->stream);
+    c->prof_events.push_back(ev);
+}
+
+static void prof_drain(Ctx* c) {
+    for (auto& e : c->prof_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(e.stop) == hipSuccess && hipEventElapsedTime(&ms, e.start, e.stop) == hipSuccess) {
+            auto& acc = c->prof_acc[c->prof_names[e.name_id]];
+            acc.first += 1;
+            acc.second += ms;
+        }
+        c->event_pool.push_back(e.start);
+        c->event_pool.push_back(e.stop);
+    }
+    c->prof_events.clear();
+}
+
+}  // namespace gsx
+
+using gsx::Ctx;
+
+#define CTX_OR_FAIL(ctx)                                                     \
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);                                    \
+    if (!c) return gsx::fail(nullptr, GSX_E_INVALID, "%s: ctx is NULL", __func__)
+
+extern "C" {
+
+int gsx_abi_version(void) { return GSX_ABI_VERSION; }
+
+int gsx_create(int device_id, gsx_ctx** out) {
+    if (!out) return gsx::fail(nullptr, GSX_E_INVALID, "gsx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return gsx::fail(nullptr, GSX_E_HIP, "gsx_create: no HIP device (%s); libgsx has no CPU fallback",
+                         e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count)
+        return gsx::fail(nullptr, GSX_E_INVALID, "gsx_create: device %d out of range [0,%d)", device_id, count);
+    hipDeviceProp_t prop;
+    GSX_HIP(nullptr, hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return gsx::fail(nullptr, GSX_E_HIP, "gsx_create: device %d is %s; this library carries gfx950 code only",
+                         device_id, prop.gcnArchName);
+    GSX_HIP(nullptr, hipSetDevice(device_id));
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return gsx::fail(nullptr, GSX_E_INVALID, "gsx_create: out of host memory");
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return gsx::fail(nullptr, GSX_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = reinterpret_cast<gsx_ctx*>(c);
+    return GSX_OK;
+}
+
+void gsx_destroy(gsx_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    gsx::prof_drain(c);
+    for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
+    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->d_views, &c->segpool, &c->stage, &c->errflag, &c->cnt, &c->fv,
+                           &c->keys, &c->labels})
+        b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gsx_last_error(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c ? c->err.c_str() : gsx::g_err.c_str();
+}
+
+void* gsx_stream(gsx_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return c ? (void*)c->stream : nullptr;
+}
+
+int gsx_synchronize(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+// ---- scene ---------------------------------------------------------------------------------------
+static int alloc_positions(Ctx* c, int64_t n) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * (size_t)(n > 0 ? n : 1);
+    GSX_HIP(c, c->x.ensure(bytes));
+    GSX_HIP(c, c->y.ensure(bytes));
+    GSX_HIP(c, c->z.ensure(bytes));
+    c->n = n;
+    c->n_pad = (n + 255) / 256 * 256;
+    c->vote_begun = false;  // planes are sized by n: a new scene needs a new vote_begin
+    c->labels_valid = false;
+    return GSX_OK;
+}
+
+int gsx_upload_positions(gsx_ctx* ctx, int64_t n, const float* x, const float* y, const float* z) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && (!x || !y || !z))) return gsx::fail(c, GSX_E_INVALID, "upload_positions: bad arguments");
+    if (n > (int64_t)1 << 31) return gsx::fail(c, GSX_E_UNSUPPORTED, "upload_positions: n > 2^31");
+    int rc = alloc_positions(c, n);
+    if (rc) return rc;
+    if (n == 0) return GSX_OK;
+    GSX_HIP(c, hipMemcpyAsync(c->x.p, x, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->y.p, y, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(c->z.p, z, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int gsx_upload_positions_strided(gsx_ctx* ctx, int64_t n, const void* base, int64_t stride_bytes, int64_t off_x,
+                                 int64_t off_y, int64_t off_z) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && !base) || stride_bytes < 4 || off_x < 0 || off_y < 0 || off_z < 0)
+        return gsx::fail(c, GSX_E_INVALID, "upload_positions_strided: bad arguments");
+    // AoS -> SoA transpose on the host (rows are 248+ bytes in a 3DGS PLY; only 12 are wanted)
+    std::vector<float> sx((size_t)n), sy((size_t)n), sz((size_t)n);
+    const char* b = static_cast<const char*>(base);
+    for (int64_t i = 0; i < n; ++i) {
+        const char* row = b + i * stride_bytes;
+        std::memcpy(&sx[i], row + off_x, 4);
+        std::memcpy(&sy[i], row + off_y, 4);
+        std::memcpy(&sz[i], row + off_z, 4);
+    }
+    return gsx_upload_positions(ctx, n, sx.data(), sy.data(), sz.data());
+}
+
+int64_t gsx_num_gaussians(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c ? c->n : 0;
+}
+
+// ---- projection probe ----------------------------------------------------------------------------
+int gsx_project_one(gsx_ctx* ctx, const float pos[3], const gsx_camera* cam, int32_t* x, int32_t* y,
+                    int32_t* visible) {
+    CTX_OR_FAIL(ctx);
+    if (!pos || !cam || !x || !y || !visible) return gsx::fail(c, GSX_E_INVALID, "project_one: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    gsx::DevBuf tmp;
+    GSX_HIP(c, tmp.ensure(3 * sizeof(float)));
+    hipError_t e = hipMemcpy(tmp.p, pos, 3 * sizeof(float), hipMemcpyHostToDevice);
+    int rc = GSX_OK;
+    if (e != hipSuccess) rc = gsx::fail(c, GSX_E_HIP, "project_one: H2D failed: %s", hipGetErrorString(e));
+    if (!rc) rc = gsx::project_all(c, cam, tmp.as<float>(), tmp.as<float>() + 1, tmp.as<float>() + 2, 1, x, y);
+    tmp.release();
+    if (!rc) *visible = (*x >= 0) ? 1 : 0;
+    return rc;
+}
+
+int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y) {
+    CTX_OR_FAIL(ctx);
+    if (!cam || !x || !y) return gsx::fail(c, GSX_E_INVALID, "project_all: NULL argument");
+    return gsx::project_all(c, cam, c->x.as<float>(), c->y.as<float>(), c->z.as<float>(), c->n, x, y);
+}
+
+// ---- vote ----------------------------------------------------------------------------------------
+int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t total_views) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_begin(c, n_classes, first_view, total_views);
+}
+int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
+                  int32_t seg_h, int32_t img_w, int32_t img_h) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_view(c, cam, seg, false, seg_dtype, seg_w, seg_h, img_w, img_h);
+}
+int gsx_vote_view_device(gsx_ctx* ctx, const gsx_camera* cam, const void* seg_dev, int32_t seg_dtype, int32_t seg_w,
+                         int32_t seg_h, int32_t img_w, int32_t img_h) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_view(c, cam, seg_dev, true, seg_dtype, seg_w, seg_h, img_w, img_h);
+}
+int32_t gsx_vote_num_views(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c ? (int32_t)c->views.size() : 0;
+}
+int gsx_vote_rewind(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_rewind(c);
+}
+int gsx_vote_finalize(gsx_ctx* ctx, int32_t* labels_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_finalize(c, labels_out);
+}
+void* gsx_vote_labels_device(gsx_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return (c && c->labels_valid) ? c->labels.p : nullptr;
+}
+int gsx_vote_flush(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_flush(c);
+}
+void* gsx_vote_counts_device(gsx_ctx* ctx, int64_t* n_int32_words) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !c->vote_begun) return nullptr;
+    if (n_int32_words) *n_int32_words = (int64_t)c->bins * c->n_pad * (c->wide ? 2 : 1) / 4;
+    return c->cnt.p;
+}
+int gsx_vote_tiebreak_keys(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_tiebreak_keys(c);
+}
+void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !c->vote_begun) return nullptr;
+    if (n_int32_words) *n_int32_words = c->n_pad;
+    return c->keys.p;
+}
+int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_labels_from_keys(c, labels_out);
+}
+int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_debug_planes(c, counts_out, first_out);
+}
+
+// ---- profiling -----------------------------------------------------------------------------------
+int gsx_profile_enable(gsx_ctx* ctx, int on) {
+    CTX_OR_FAIL(ctx);
+    c->prof_on = on != 0;
+    return GSX_OK;
+}
+int gsx_profile_reset(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    GSX_HIP(c, hipSetDevice(c->device));
+    gsx::prof_drain(c);
+    c->prof_acc.clear();
+    return GSX_OK;
+}
+int gsx_profile_get(gsx_ctx* ctx, const char* name, int64_t* launches, double* total_ms) {
+    CTX_OR_FAIL(ctx);
+    if (!name) return gsx::fail(c, GSX_E_INVALID, "profile_get: name is NULL");
+    GSX_HIP(c, hipSetDevice(c->device));
+    gsx::prof_drain(c);
+    auto it = c->prof_acc.find(name);
+    if (launches) *launches = it == c->prof_acc.end() ? 0 : it->second.first;
+    if (total_ms) *total_ms = it == c->prof_acc.end() ? 0.0 : it->second.second;
+    return GSX_OK;
+}
+
+}  // extern "C"

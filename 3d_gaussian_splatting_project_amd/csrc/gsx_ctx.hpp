@@ -1,0 +1,130 @@
+// Internal (non-ABI) state of libgsx.so.  Everything here is private to the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gsx.h"
+
+namespace gsx {
+
+// ---- error plumbing ----------------------------------------------------------------------------
+void set_global_error(const char* fmt, ...);
+struct Ctx;
+int fail(Ctx* c, int code, const char* fmt, ...);
+
+#define GSX_HIP(ctx, call)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (call);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return gsx::fail((ctx), GSX_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), \
+                             __FILE__, __LINE__);                                                  \
+    } while (0)
+
+// ---- device buffer: grows, never shrinks ---------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {  // contents are NOT preserved on growth
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- per-view descriptor read by the kernels through scalar (wave-uniform) loads ------------------
+struct alignas(16) ViewDesc {
+    double R[9];       // cameras.json rotation, row-major                         (dls.py:60)
+    double t[3];       // (-R) @ p in the dgemv association of the oracle           (dls.py:66)
+    double fx, fy;     //                                                           (dls.py:54-55)
+    double half_w, half_h;  // width/2, height/2                                    (dls.py:76-77)
+    double width, height;   // bounds of the visibility test                        (dls.py:80)
+    double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
+    long long seg_off;      // byte offset of this view's u8 map in the seg pool
+    int seg_w, seg_h;
+    int unit_scale;  // both scales are exactly 1.0 -> int(x*1.0) == x, clamp is a no-op
+    int pad_;
+};
+
+struct ProfEvent {
+    int name_id;
+    hipEvent_t start, stop;
+};
+
+struct Ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene
+    int64_t n = 0;
+    int64_t n_pad = 0;  // n rounded up to 256: row pitch of the vote planes
+    DevBuf x, y, z;     // SoA f32 positions
+
+    // vote
+    bool vote_begun = false;
+    int n_classes = 0, bins = 0;
+    int first_view = 0, total_views = 0;
+    bool wide = false;  // 16-bit plane counters (total_views > 255)
+    std::vector<ViewDesc> views;
+    bool views_dirty = true;  // host views newer than d_views
+    DevBuf d_views;
+    DevBuf segpool;
+    size_t seg_used = 0;
+    DevBuf stage;  // raw int32/int64 map staging for gsx_vote_view
+    DevBuf errflag;
+    int n_flushed = 0;         // views [0, n_flushed) are already in the planes
+    bool planes_valid = false;  // planes hold votes (zeroed at begin/rewind)
+    bool planes_zero = false;   // planes are known to be all-zero
+    DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
+    DevBuf keys, labels;        // [n_pad] int32
+    bool labels_valid = false;
+
+    // profiling
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfEvent> prof_events;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<int64_t, double>> prof_acc;
+};
+
+// RAII: brackets one kernel launch with events when profiling is on
+struct ProfScope {
+    Ctx* c;
+    ProfEvent ev{};
+    bool active = false;
+    ProfScope(Ctx* ctx, const char* name);
+    ~ProfScope();
+};
+
+// vote.hip
+int vote_begin(Ctx* c, int n_classes, int first_view, int total_views);
+int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device, int seg_dtype, int seg_w,
+              int seg_h, int img_w, int img_h);
+int vote_rewind(Ctx* c);
+int vote_finalize(Ctx* c, int32_t* labels_out);
+int vote_flush(Ctx* c);
+int vote_tiebreak_keys(Ctx* c);
+int vote_labels_from_keys(Ctx* c, int32_t* labels_out);
+int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out);
+int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
+                int32_t* x_host, int32_t* y_host);
+void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);
+
+}  // namespace gsx

@@ -1,0 +1,628 @@
+// vote.hip — majority-vote labeler kernels for gfx950 (MI355X) and their host drivers.
+//
+// Replaces the double loop of assign_labels (deep_learning_segmentation.py:255-295) and its arg-max
+// (:297-308); project() restates project_gaussian (:43-82) operation for operation in fp64.
+// This translation unit MUST be compiled with -ffp-contract=off: every fma below is explicit and
+// every other product/sum must round separately, exactly as the reference's Python floats do.
+//
+// Data layout in HBM
+//   positions      SoA  x[n], y[n], z[n] f32                      (coalesced 4 B/lane loads)
+//   views          ViewDesc[V], 192 B each, wave-uniform -> scalar loads, operands live in SGPRs
+//   seg pool       u8 maps, value = label+1 (bin index), one after another; 1 B gathers
+//   planes         cnt[bins][n_pad], fv[bins][n_pad]  u8 (total_views <= 255) or u16: bin-major so
+//                  that a wave's 64 Gaussians touch 64 consecutive elements of a row
+//   keys, labels   int32[n_pad]
+//
+// Kernel design (Gaussian-major, all staged views in one launch)
+//   one thread = one Gaussian; it walks the views in REVERSE order and keeps its private vote
+//   histogram in LDS (row stride an odd number of dwords: a wave that votes one label hits 32
+//   different banks).  Reverse order makes the reference's tie rule an online rule: a label that
+//   reaches a count >= the best count so far takes over; the label whose FIRST vote (in forward
+//   order) is earliest among the max-count labels is the last one to do so.  See DESIGN.md §3.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+
+#include "gsx_ctx.hpp"
+
+namespace gsx {
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxBatch = 255;  // views per fused launch: LDS counters are 8 bit
+
+// -------------------------------------------------------------------------------------------------
+// device: project_gaussian + seg-map addressing
+// -------------------------------------------------------------------------------------------------
+// OpenBLAS dgemv association of `R @ v` for a C-contiguous 3x3 (oracle/vote_oracle.c, header)
+__device__ __forceinline__ double row_dot(const double* __restrict__ Rr, double v0, double v1, double v2) {
+    return __builtin_fma(Rr[2], v2, __builtin_fma(Rr[0], v0, Rr[1] * v1));
+}
+
+// returns false where the reference returns None (dls.py:72-73, 80-82)
+__device__ __forceinline__ bool project(const ViewDesc& vd, double X, double Y, double Z, int& xi, int& yi) {
+    const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
+    if (!(pc2 > 0.0)) return false;  // `pc2 <= 0` -> None; a NaN depth fails the bounds test below anyway
+    const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
+    const double pc1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
+    const double px = (vd.fx * pc0) / pc2 + vd.half_w;  // dls.py:76
+    const double py = (vd.fy * pc1) / pc2 + vd.half_h;  // dls.py:77
+    if (!((0.0 <= px) && (px < vd.width) && (0.0 <= py) && (py < vd.height))) return false;  // :80
+    xi = (int)px;  // int() truncation, :81
+    yi = (int)py;
+    return true;
+}
+
+// byte offset of the voted pixel inside the seg pool, or -1 (dls.py:276-288)
+__device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, double Y, double Z) {
+    int xi, yi;
+    if (!project(vd, X, Y, Z, xi, yi)) return -1;
+    if (!vd.unit_scale) {
+        const double xs = trunc((double)xi * vd.wscale);  // :281
+        const double ys = trunc((double)yi * vd.hscale);  // :282
+        xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
+        yi = ys > (double)(vd.seg_h - 1) ? vd.seg_h - 1 : (int)ys;  // :286
+    }
+    return vd.seg_off + (long long)yi * vd.seg_w + xi;
+}
+
+__global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, long long n,
+                                                         const ViewDesc* __restrict__ vd, int* __restrict__ ox,
+                                                         int* __restrict__ oy) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int xi, yi;
+    const bool vis = project(*vd, (double)x[i], (double)y[i], (double)z[i], xi, yi);
+    ox[i] = vis ? xi : -1;
+    oy[i] = vis ? yi : -1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// seg-map packing: int32/int64/u8 host dtype -> u8 bin index (label+1), with range validation
+// -------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ in, uint8_t* __restrict__ out,
+                                                          long long npix, int bins, int* __restrict__ err) {
+    // 4 pixels per thread: 16 B (int32) in, 4 B out per lane
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long base = q * 4;
+    if (base >= npix) return;
+    int bad = 0;
+    if (base + 4 <= npix) {
+        T v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = in[base + k];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long b = (long long)v[k] + (sizeof(T) == 1 ? 0 : 1);
+            bad |= (b < 0) | (b >= bins);
+            packed |= (uint32_t)(b & 0xff) << (8 * k);
+        }
+        if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+            reinterpret_cast<uint32_t*>(out)[q] = packed;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[base + k] = (uint8_t)(packed >> (8 * k));
+        }
+    } else {
+        for (long long p = base; p < npix; ++p) {
+            const long long b = (long long)in[p] + (sizeof(T) == 1 ? 0 : 1);
+            bad |= (b < 0) | (b >= bins);
+            out[p] = (uint8_t)b;
+        }
+    }
+    if (bad) atomicOr(err, 1);
+}
+
+// -------------------------------------------------------------------------------------------------
+// fused vote, single GPU / single batch: labels straight out of the kernel
+// -------------------------------------------------------------------------------------------------
+struct FusedParams {
+    const float* x;
+    const float* y;
+    const float* z;
+    long long n;
+    const ViewDesc* views;  // the batch's views
+    int nviews;             // <= kMaxBatch
+    const uint8_t* pool;
+    int bins;
+    int stride_dw;  // LDS row stride in dwords (odd)
+};
+
+template <int U>
+__global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, int* __restrict__ labels) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
+    uint8_t* h = reinterpret_cast<uint8_t*>(row);
+
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    // lanes past the end carry NaN: every comparison in project() fails, they never vote
+    const double X = valid ? (double)p.x[i] : __builtin_nan("");
+    const double Y = valid ? (double)p.y[i] : 0.0;
+    const double Z = valid ? (double)p.z[i] : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+
+    int best = -1;  // bin of the current winner
+    int bestc = 0;
+    for (int vb = p.nviews; vb > 0; vb -= U) {  // views vb-1, vb-2, .. (reverse order)
+        int bin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            bin[u] = -1;
+            if (v >= 0) {  // wave-uniform
+                const long long off = seg_index(p.views[v], X, Y, Z);
+                if (off >= 0) bin[u] = pool[off];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (bin[u] >= 0) {
+                const int c = h[bin[u]] + 1;  // dls.py:295
+                h[bin[u]] = (uint8_t)c;
+                if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
+                    bestc = c;
+                    best = bin[u];
+                }
+            }
+        }
+    }
+    if (valid) labels[i] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
+}
+
+// -------------------------------------------------------------------------------------------------
+// fused vote, planes mode (multi-GPU exchange, or more than kMaxBatch views): the batch's votes
+// are merged into the global planes cnt[bins][n_pad] / fv[bins][n_pad].
+// LDS word per bin: count << 8 | local index of the earliest view that voted it.
+// fv code = FVMAX - global view index of the first vote (larger = earlier; 0 = no vote).
+// -------------------------------------------------------------------------------------------------
+template <int U, typename PT>
+__global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, PT* __restrict__ cnt,
+                                                                   PT* __restrict__ fv, long long n_pad,
+                                                                   int view_base, int fresh) {
+    constexpr int FVMAX = sizeof(PT) == 1 ? 255 : 65535;
+    extern __shared__ uint32_t lds[];
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;
+    uint16_t* h = reinterpret_cast<uint16_t*>(row);
+
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const double X = valid ? (double)p.x[i] : __builtin_nan("");
+    const double Y = valid ? (double)p.y[i] : 0.0;
+    const double Z = valid ? (double)p.z[i] : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+
+    for (int vb = p.nviews; vb > 0; vb -= U) {
+        int bin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            bin[u] = -1;
+            if (v >= 0) {
+                const long long off = seg_index(p.views[v], X, Y, Z);
+                if (off >= 0) bin[u] = pool[off];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (bin[u] >= 0) {
+                const int v = vb - 1 - u;
+                const unsigned w = h[bin[u]];
+                h[bin[u]] = (uint16_t)(((w & 0xff00u) + 0x100u) | (unsigned)v);  // reverse order: last write = earliest view
+            }
+        }
+    }
+    if (!valid) return;
+    for (int b = 0; b < p.bins; ++b) {
+        const unsigned w = h[b];
+        const unsigned c = w >> 8;
+        const unsigned code = c ? (unsigned)(FVMAX - (view_base + (int)(w & 0xffu))) : 0u;
+        const long long at = (long long)b * n_pad + i;
+        if (fresh) {
+            cnt[at] = (PT)c;
+            fv[at] = (PT)code;
+        } else if (c) {
+            cnt[at] = (PT)(cnt[at] + c);
+            const unsigned old = fv[at];
+            if (code > old) fv[at] = (PT)code;
+        }
+    }
+}
+
+// per Gaussian: among the bins holding the (global) maximum count, the one this rank saw first
+template <typename PT>
+__global__ __launch_bounds__(kBlock) void vote_keys_kernel(const PT* __restrict__ cnt, const PT* __restrict__ fv,
+                                                           long long n, long long n_pad, int bins,
+                                                           int* __restrict__ keys) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    unsigned M = 0;
+    int key = 0;
+    for (int b = 0; b < bins; ++b) {
+        const unsigned c = cnt[(long long)b * n_pad + i];
+        if (c == 0 || c < M) continue;
+        const unsigned f = fv[(long long)b * n_pad + i];
+        const int k = f ? (int)((f << 8) | (unsigned)b) : 0;
+        if (c > M) {
+            M = c;
+            key = k;
+        } else if (k > key) {
+            key = k;
+        }
+    }
+    keys[i] = key;
+}
+
+__global__ __launch_bounds__(kBlock) void vote_labels_kernel(const int* __restrict__ keys, long long n,
+                                                             int* __restrict__ labels) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int k = keys[i];
+    labels[i] = k ? (k & 0xff) - 1 : -1;
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h) {
+    std::memset(&vd, 0, sizeof vd);
+    double nR[9];
+    for (int k = 0; k < 9; ++k) {
+        vd.R[k] = cam->R[k];
+        nR[k] = -cam->R[k];  // t = -R @ p: unary minus first (dls.py:66)
+    }
+    for (int r = 0; r < 3; ++r)
+        vd.t[r] = std::fma(nR[3 * r + 2], cam->p[2], std::fma(nR[3 * r + 0], cam->p[0], nR[3 * r + 1] * cam->p[1]));
+    vd.fx = cam->fx;
+    vd.fy = cam->fy;
+    vd.half_w = (double)cam->width / 2.0;
+    vd.half_h = (double)cam->height / 2.0;
+    vd.width = (double)cam->width;
+    vd.height = (double)cam->height;
+    vd.wscale = (double)seg_w / (double)img_w;
+    vd.hscale = (double)seg_h / (double)img_h;
+    vd.seg_w = seg_w;
+    vd.seg_h = seg_h;
+    vd.unit_scale = (vd.wscale == 1.0 && vd.hscale == 1.0) ? 1 : 0;
+}
+
+static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
+                int32_t* x_host, int32_t* y_host) {
+    if (n <= 0) return GSX_OK;
+    GSX_HIP(c, hipSetDevice(c->device));
+    ViewDesc vd;
+    fill_view_desc(vd, cam, 1, 1, 1, 1);
+    DevBuf dvd, ox, oy;
+    GSX_HIP(c, dvd.ensure(sizeof vd));
+    GSX_HIP(c, ox.ensure(sizeof(int) * n));
+    GSX_HIP(c, oy.ensure(sizeof(int) * n));
+    int rc = GSX_OK;
+    hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        ProfScope ps(c, "project");
+        hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+                           dvd.as<ViewDesc>(), ox.as<int>(), oy.as<int>());
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(x_host, ox.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(y_host, oy.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) rc = fail(c, GSX_E_HIP, "project_all: %s", hipGetErrorString(e));
+    dvd.release();
+    ox.release();
+    oy.release();
+    return rc;
+}
+
+int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
+    if (n_classes < 1 || n_classes > 255)
+        return fail(c, GSX_E_UNSUPPORTED, "vote_begin: n_classes=%d outside [1,255] (u8 seg maps)", n_classes);
+    if (first_view < 0 || total_views < 1 || total_views > 65535 || first_view >= total_views)
+        return fail(c, GSX_E_INVALID, "vote_begin: first_view=%d total_views=%d (need 0 <= first < total <= 65535)",
+                    first_view, total_views);
+    GSX_HIP(c, hipSetDevice(c->device));
+    c->n_classes = n_classes;
+    c->bins = n_classes + 1;
+    c->first_view = first_view;
+    c->total_views = total_views;
+    c->wide = total_views > 255;
+    c->views.clear();
+    c->views_dirty = true;
+    c->seg_used = 0;
+    c->n_flushed = 0;
+    c->planes_valid = false;
+    c->planes_zero = false;
+    c->labels_valid = false;
+    GSX_HIP(c, c->errflag.ensure(sizeof(int)));
+    GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
+    c->vote_begun = true;
+    return GSX_OK;
+}
+
+static int pool_reserve(Ctx* c, size_t need) {
+    if (need <= c->segpool.cap) return GSX_OK;
+    size_t cap = c->segpool.cap ? c->segpool.cap : ((size_t)64 << 20);
+    while (cap < need) cap *= 2;
+    void* np = nullptr;
+    GSX_HIP(c, hipMalloc(&np, cap));
+    if (c->seg_used) {
+        hipError_t e = hipMemcpyAsync(np, c->segpool.p, c->seg_used, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            return fail(c, GSX_E_HIP, "seg pool growth copy failed: %s", hipGetErrorString(e));
+        }
+    }
+    c->segpool.release();
+    c->segpool.p = np;
+    c->segpool.cap = cap;
+    return GSX_OK;
+}
+
+int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device, int seg_dtype, int seg_w, int seg_h,
+              int img_w, int img_h) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_view before vote_begin");
+    if (!cam || !seg) return fail(c, GSX_E_INVALID, "vote_view: NULL argument");
+    if (seg_w < 1 || seg_h < 1 || img_w < 1 || img_h < 1)
+        return fail(c, GSX_E_INVALID, "vote_view: sizes must be positive (seg %dx%d, image %dx%d)", seg_w, seg_h, img_w,
+                    img_h);
+    if (seg_dtype != GSX_SEG_I32 && seg_dtype != GSX_SEG_I64 && seg_dtype != GSX_SEG_U8)
+        return fail(c, GSX_E_INVALID, "vote_view: unknown seg_dtype %d", seg_dtype);
+    if (c->first_view + (int)c->views.size() >= c->total_views)
+        return fail(c, GSX_E_RANGE, "vote_view: more views than total_views=%d announced at vote_begin", c->total_views);
+    GSX_HIP(c, hipSetDevice(c->device));
+
+    const long long npix = (long long)seg_w * seg_h;
+    const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
+    const size_t off = (c->seg_used + 255) / 256 * 256;  // 256-B aligned maps
+    int rc = pool_reserve(c, off + (size_t)npix);
+    if (rc) return rc;
+    const void* src = seg;
+    if (!seg_on_device) {
+        GSX_HIP(c, c->stage.ensure(esz * npix));
+        GSX_HIP(c, hipMemcpyAsync(c->stage.p, seg, esz * npix, hipMemcpyHostToDevice, c->stream));
+        src = c->stage.p;
+    }
+    uint8_t* dst = c->segpool.as<uint8_t>() + off;
+    const unsigned grid = grid_for((npix + 3) / 4);
+    {
+        ProfScope ps(c, "seg_pack");
+        if (seg_dtype == GSX_SEG_I32)
+            hipLaunchKernelGGL(seg_pack_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int32_t*)src, dst,
+                               npix, c->bins, c->errflag.as<int>());
+        else if (seg_dtype == GSX_SEG_I64)
+            hipLaunchKernelGGL(seg_pack_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int64_t*)src, dst,
+                               npix, c->bins, c->errflag.as<int>());
+        else
+            hipLaunchKernelGGL(seg_pack_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const uint8_t*)src, dst,
+                               npix, c->bins, c->errflag.as<int>());
+    }
+    GSX_HIP(c, hipGetLastError());
+    int bad = 0;
+    GSX_HIP(c, hipMemcpyAsync(&bad, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad) {
+        GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
+        return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
+    }
+    ViewDesc vd;
+    fill_view_desc(vd, cam, seg_w, seg_h, img_w, img_h);
+    vd.seg_off = (long long)off;
+    c->views.push_back(vd);
+    c->views_dirty = true;
+    c->seg_used = off + (size_t)npix;
+    c->labels_valid = false;
+    return GSX_OK;
+}
+
+static int sync_views(Ctx* c) {
+    if (!c->views_dirty) return GSX_OK;
+    const size_t bytes = sizeof(ViewDesc) * (c->views.empty() ? 1 : c->views.size());
+    GSX_HIP(c, c->d_views.ensure(bytes));
+    if (!c->views.empty())
+        GSX_HIP(c, hipMemcpyAsync(c->d_views.p, c->views.data(), sizeof(ViewDesc) * c->views.size(),
+                                  hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));  // c->views may be reallocated by the next push_back
+    c->views_dirty = false;
+    return GSX_OK;
+}
+
+static inline int odd_dwords(int bytes) {
+    int dw = (bytes + 3) / 4;
+    return dw | 1;
+}
+
+static int ensure_planes(Ctx* c) {
+    const size_t esz = c->wide ? 2 : 1;
+    const size_t bytes = (size_t)c->bins * (size_t)c->n_pad * esz;
+    const bool grew = bytes > c->cnt.cap || bytes > c->fv.cap;
+    GSX_HIP(c, c->cnt.ensure(bytes ? bytes : 4));
+    GSX_HIP(c, c->fv.ensure(bytes ? bytes : 4));
+    if (grew || !(c->planes_valid || c->planes_zero)) {
+        GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));
+        GSX_HIP(c, hipMemsetAsync(c->fv.p, 0, bytes, c->stream));
+        c->planes_zero = true;
+        c->planes_valid = false;
+    }
+    return GSX_OK;
+}
+
+int vote_rewind(Ctx* c) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_rewind before vote_begin");
+    GSX_HIP(c, hipSetDevice(c->device));
+    c->n_flushed = 0;
+    c->labels_valid = false;
+    if (c->planes_valid) {
+        const size_t bytes = (size_t)c->bins * (size_t)c->n_pad * (c->wide ? 2 : 1);
+        GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));
+        GSX_HIP(c, hipMemsetAsync(c->fv.p, 0, bytes, c->stream));
+        c->planes_valid = false;
+        c->planes_zero = true;
+    }
+    return GSX_OK;
+}
+
+template <class K>
+static int set_lds(Ctx* c, K kernel, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(c, GSX_E_UNSUPPORTED, "vote: %zu B of LDS per workgroup exceeds 160 KiB", bytes);
+    GSX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)bytes));
+    return GSX_OK;
+}
+
+static constexpr int kUnroll = 4;
+
+// merge views [n_flushed, size) into the planes, kMaxBatch at a time
+int vote_flush(Ctx* c) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_flush before vote_begin");
+    GSX_HIP(c, hipSetDevice(c->device));
+    int rc = sync_views(c);
+    if (rc) return rc;
+    rc = ensure_planes(c);
+    if (rc) return rc;
+    const int nv = (int)c->views.size();
+    if (c->n <= 0) {
+        c->n_flushed = nv;
+        return GSX_OK;
+    }
+    FusedParams p{};
+    p.x = c->x.as<float>();
+    p.y = c->y.as<float>();
+    p.z = c->z.as<float>();
+    p.n = c->n;
+    p.pool = c->segpool.as<uint8_t>();
+    p.bins = c->bins;
+    p.stride_dw = odd_dwords(c->bins * 2);
+    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+    while (c->n_flushed < nv) {
+        const int batch = std::min(kMaxBatch, nv - c->n_flushed);
+        p.views = c->d_views.as<ViewDesc>() + c->n_flushed;
+        p.nviews = batch;
+        const int view_base = c->first_view + c->n_flushed;
+        const int fresh = c->planes_zero ? 1 : 0;
+        ProfScope ps(c, "vote_fused_planes");
+        if (c->wide) {
+            auto k = vote_fused_planes_kernel<kUnroll, uint16_t>;
+            if ((rc = set_lds(c, k, lds))) return rc;
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint16_t>(),
+                               c->fv.as<uint16_t>(), (long long)c->n_pad, view_base, fresh);
+        } else {
+            auto k = vote_fused_planes_kernel<kUnroll, uint8_t>;
+            if ((rc = set_lds(c, k, lds))) return rc;
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint8_t>(),
+                               c->fv.as<uint8_t>(), (long long)c->n_pad, view_base, fresh);
+        }
+        GSX_HIP(c, hipGetLastError());
+        c->planes_zero = false;
+        c->planes_valid = true;
+        c->n_flushed += batch;
+    }
+    return GSX_OK;
+}
+
+int vote_tiebreak_keys(Ctx* c) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_tiebreak_keys before vote_begin");
+    GSX_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_planes(c);
+    if (rc) return rc;
+    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    GSX_HIP(c, hipMemsetAsync(c->keys.p, 0, sizeof(int) * (size_t)c->n_pad, c->stream));
+    if (c->n <= 0) return GSX_OK;
+    ProfScope ps(c, "vote_keys");
+    if (c->wide)
+        hipLaunchKernelGGL(vote_keys_kernel<uint16_t>, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream,
+                           c->cnt.as<uint16_t>(), c->fv.as<uint16_t>(), (long long)c->n, (long long)c->n_pad, c->bins,
+                           c->keys.as<int>());
+    else
+        hipLaunchKernelGGL(vote_keys_kernel<uint8_t>, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream,
+                           c->cnt.as<uint8_t>(), c->fv.as<uint8_t>(), (long long)c->n, (long long)c->n_pad, c->bins,
+                           c->keys.as<int>());
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+static int labels_to_host(Ctx* c, int32_t* labels_out) {
+    c->labels_valid = true;
+    if (labels_out && c->n > 0)
+        GSX_HIP(c, hipMemcpyAsync(labels_out, c->labels.p, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int vote_labels_from_keys(Ctx* c, int32_t* labels_out) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_labels_from_keys before vote_begin");
+    if (c->keys.cap < sizeof(int) * (size_t)c->n_pad) return fail(c, GSX_E_STATE, "vote_labels_from_keys before vote_tiebreak_keys");
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    if (c->n > 0) {
+        ProfScope ps(c, "vote_labels");
+        hipLaunchKernelGGL(vote_labels_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->keys.as<int>(),
+                           (long long)c->n, c->labels.as<int>());
+        GSX_HIP(c, hipGetLastError());
+    }
+    return labels_to_host(c, labels_out);
+}
+
+int vote_finalize(Ctx* c, int32_t* labels_out) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_finalize before vote_begin");
+    GSX_HIP(c, hipSetDevice(c->device));
+    const int nv = (int)c->views.size();
+    if (c->n_flushed == 0 && nv <= kMaxBatch) {
+        // single batch, nothing in the planes: labels come straight out of the fused kernel
+        int rc = sync_views(c);
+        if (rc) return rc;
+        GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+        if (c->n > 0) {
+            FusedParams p{};
+            p.x = c->x.as<float>();
+            p.y = c->y.as<float>();
+            p.z = c->z.as<float>();
+            p.n = c->n;
+            p.views = c->d_views.as<ViewDesc>();
+            p.nviews = nv;
+            p.pool = c->segpool.as<uint8_t>();
+            p.bins = c->bins;
+            p.stride_dw = odd_dwords(c->bins);
+            const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+            auto k = vote_fused_labels_kernel<kUnroll>;
+            if ((rc = set_lds(c, k, lds))) return rc;
+            ProfScope ps(c, "vote_fused_labels");
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->labels.as<int>());
+            GSX_HIP(c, hipGetLastError());
+        }
+        return labels_to_host(c, labels_out);
+    }
+    int rc = vote_flush(c);
+    if (rc) return rc;
+    if ((rc = vote_tiebreak_keys(c))) return rc;
+    return vote_labels_from_keys(c, labels_out);
+}
+
+int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
+    if (!c->vote_begun || !(c->planes_valid || c->planes_zero)) return fail(c, GSX_E_STATE, "vote_debug_planes: no planes");
+    if (!counts_out || !first_out) return fail(c, GSX_E_INVALID, "vote_debug_planes: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    const size_t esz = c->wide ? 2 : 1;
+    const size_t elems = (size_t)c->bins * (size_t)c->n_pad;
+    std::vector<uint8_t> tmp(elems * esz);
+    for (int which = 0; which < 2; ++which) {
+        GSX_HIP(c, hipMemcpyAsync(tmp.data(), which ? c->fv.p : c->cnt.p, elems * esz, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        uint16_t* out = which ? first_out : counts_out;
+        for (int b = 0; b < c->bins; ++b)
+            for (int64_t i = 0; i < c->n; ++i) {
+                const size_t at = (size_t)b * c->n_pad + i;
+                out[(size_t)b * c->n + i] = c->wide ? reinterpret_cast<uint16_t*>(tmp.data())[at] : tmp[at];
+            }
+    }
+    return GSX_OK;
+}
+
+}  // namespace gsx

@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's labeler interface on top of libgsx.so.
+
+Same names, argument meaning and results as /root/reference/deep_learning_segmentation.py:
+load_cameras (:17), project_gaussian (:43), assign_labels (:241) — except that assign_labels
+takes its segmentation maps from a callable / directory instead of running a model, because the
+2-D segmentation networks are outside this library.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import Camera, check
+
+
+def load_cameras(camera_file):
+    """cameras.json -> list of dicts (reference: deep_learning_segmentation.py:17-22)."""
+    with open(camera_file, "r") as f:
+        return json.load(f)
+
+
+class Context:
+    """One GPU (gsx_ctx).  device: HIP ordinal; defaults to LOCAL_RANK or 0."""
+
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self._lib = _lib.lib()
+        h = C.c_void_p()
+        check(self._lib.gsx_create(int(device), C.byref(h)))
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.gsx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene ---------------------------------------------------------------------------------
+    def upload_positions(self, positions):
+        """positions: (N,3) float array, or a structured array with a 'position' field
+        (the reference's `gaussians`, deep_learning_segmentation.py:33-38)."""
+        if getattr(positions, "dtype", None) is not None and positions.dtype.names and "position" in positions.dtype.names:
+            positions = positions["position"]
+        pos = np.asarray(positions, dtype=np.float32)
+        if pos.ndim != 2 or pos.shape[1] != 3:
+            raise ValueError("positions must have shape (N, 3)")
+        x = np.ascontiguousarray(pos[:, 0])
+        y = np.ascontiguousarray(pos[:, 1])
+        z = np.ascontiguousarray(pos[:, 2])
+        check(self._lib.gsx_upload_positions(self.h, len(pos), x.ctypes.data, y.ctypes.data, z.ctypes.data), self.h)
+        self.n = len(pos)
+
+    def upload_rows(self, rows, off_x, off_y, off_z):
+        """AoS rows (e.g. PLY vertex records as a 2-D uint8 array or structured array)."""
+        rows = np.ascontiguousarray(rows)
+        check(self._lib.gsx_upload_positions_strided(self.h, len(rows), rows.ctypes.data, rows.strides[0], off_x, off_y,
+                                                     off_z), self.h)
+        self.n = len(rows)
+
+    # -- projection probe ------------------------------------------------------------------------
+    def project_one(self, position, camera):
+        p = (C.c_float * 3)(*[float(v) for v in position])
+        cam = Camera.from_dict(camera)
+        x, y, vis = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self._lib.gsx_project_one(self.h, p, C.byref(cam), C.byref(x), C.byref(y), C.byref(vis)), self.h)
+        return (x.value, y.value) if vis.value else None
+
+    def project_all(self, camera):
+        cam = Camera.from_dict(camera)
+        x = np.empty(self.n, np.int32)
+        y = np.empty(self.n, np.int32)
+        check(self._lib.gsx_project_all(self.h, C.byref(cam), x.ctypes.data, y.ctypes.data), self.h)
+        return x, y
+
+    # -- vote --------------------------------------------------------------------------------------
+    def vote_begin(self, n_classes, first_view=0, total_views=255):
+        check(self._lib.gsx_vote_begin(self.h, n_classes, first_view, total_views), self.h)
+
+    def vote_view(self, camera, seg_map, image_size=None):
+        """seg_map: 2-D int array (values -1..n_classes-1) on the host, or a torch tensor on this GPU.
+        image_size: (width, height) of the input image; defaults to the map's own size."""
+        cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
+        if hasattr(seg_map, "data_ptr"):  # torch tensor on the device
+            t = seg_map.contiguous()
+            h, w = t.shape
+            dt = {"torch.int32": _lib.GSX_SEG_I32, "torch.int64": _lib.GSX_SEG_I64, "torch.uint8": _lib.GSX_SEG_U8}[str(t.dtype)]
+            iw, ih = image_size if image_size is not None else (w, h)
+            if not t.is_cuda:
+                raise ValueError("tensor seg maps must live on the GPU; pass numpy arrays for host maps")
+            check(self._lib.gsx_vote_view_device(self.h, C.byref(cam), t.data_ptr(), dt, w, h, int(iw), int(ih)), self.h)
+            return
+        seg = np.asarray(seg_map)
+        if seg.ndim != 2:
+            raise ValueError("seg_map must be 2-D")
+        if seg.dtype == np.int64:
+            dt = _lib.GSX_SEG_I64
+        elif seg.dtype == np.uint8:
+            dt = _lib.GSX_SEG_U8
+        else:
+            seg = seg.astype(np.int32, copy=False)
+            dt = _lib.GSX_SEG_I32
+        seg = np.ascontiguousarray(seg)
+        h, w = seg.shape
+        iw, ih = image_size if image_size is not None else (w, h)
+        check(self._lib.gsx_vote_view(self.h, C.byref(cam), seg.ctypes.data, dt, w, h, int(iw), int(ih)), self.h)
+
+    def vote_rewind(self):
+        check(self._lib.gsx_vote_rewind(self.h), self.h)
+
+    def vote_finalize(self, to_host=True):
+        out = np.empty(self.n, np.int32) if to_host else None
+        check(self._lib.gsx_vote_finalize(self.h, out.ctypes.data if to_host else None), self.h)
+        return out
+
+    def vote_flush(self):
+        check(self._lib.gsx_vote_flush(self.h), self.h)
+
+    def vote_tiebreak_keys(self):
+        check(self._lib.gsx_vote_tiebreak_keys(self.h), self.h)
+
+    def vote_labels_from_keys(self, to_host=True):
+        out = np.empty(self.n, np.int32) if to_host else None
+        check(self._lib.gsx_vote_labels_from_keys(self.h, out.ctypes.data if to_host else None), self.h)
+        return out
+
+    def counts_device(self):
+        n = C.c_int64()
+        p = self._lib.gsx_vote_counts_device(self.h, C.byref(n))
+        return p, n.value
+
+    def keys_device(self):
+        n = C.c_int64()
+        p = self._lib.gsx_vote_keys_device(self.h, C.byref(n))
+        return p, n.value
+
+    def debug_planes(self, bins):
+        cnt = np.empty((bins, self.n), np.uint16)
+        fv = np.empty((bins, self.n), np.uint16)
+        check(self._lib.gsx_vote_debug_planes(self.h, cnt.ctypes.data, fv.ctypes.data), self.h)
+        return cnt, fv
+
+    def synchronize(self):
+        check(self._lib.gsx_synchronize(self.h), self.h)
+
+    @property
+    def stream(self):
+        return self._lib.gsx_stream(self.h)
+
+    # -- profiling ---------------------------------------------------------------------------------
+    def profile(self, on=True):
+        check(self._lib.gsx_profile_enable(self.h, 1 if on else 0), self.h)
+        check(self._lib.gsx_profile_reset(self.h), self.h)
+
+    def profile_get(self, name):
+        n, ms = C.c_int64(), C.c_double()
+        check(self._lib.gsx_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)), self.h)
+        return n.value, ms.value
+
+
+def project_gaussian(position, camera, ctx=None):
+    """Device-side project_gaussian (reference :43-82): (x, y) ints or None."""
+    own = ctx is None
+    ctx = ctx or Context()
+    try:
+        return ctx.project_one(position, camera)
+    finally:
+        if own:
+            ctx.close()
+
+
+def assign_labels_from_maps(gaussians, cameras, segmaps, image_sizes=None, n_classes=150, ctx=None):
+    """Majority vote given per-camera segmentation maps.
+
+    cameras / segmaps / image_sizes are parallel lists over the cameras that the reference would
+    actually process (missing images already skipped, deep_learning_segmentation.py:256-259).
+    Returns int32 labels (N,), bit-identical to the reference's assign_labels (:297-308)."""
+    own = ctx is None
+    ctx = ctx or Context()
+    try:
+        ctx.upload_positions(gaussians)
+        ctx.vote_begin(n_classes, 0, max(1, len(cameras)))
+        for k, (cam, seg) in enumerate(zip(cameras, segmaps)):
+            ctx.vote_view(cam, seg, None if image_sizes is None else image_sizes[k])
+        return ctx.vote_finalize()
+    finally:
+        if own:
+            ctx.close()

@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — Gaussian·views/s labelled by the MI355X majority-vote labeler.
+
+One "step" = one full labelling pass of the hot path: every staged view (camera + segmentation map,
+already resident in HBM as the library's u8 maps) is voted for every Gaussian and the int32 label of
+each Gaussian is left in HBM.  Workload = BASELINE.json configs[2]: 3 M Gaussians, 200 views @1080p,
+150 classes (+ label -1).  With N GPUs every rank votes its own 200 views (weak scaling: the job is
+200*N views over the same 3 M Gaussians) and the per-Gaussian vote histogram is all-reduced (RCCL).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  See DESIGN.md §6 for the byte model behind "roofline".
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gaussians", type=int, default=3_000_000)
+    ap.add_argument("--views", type=int, default=200, help="views per GPU")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--classes", type=int, default=150)
+    ap.add_argument("--cpu-sample", type=int, default=400_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+
+    import torch
+    import torch.distributed as dist
+    pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+    scene = pkg.scene
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n, V, W, H = args.gaussians, args.views, args.width, args.height
+    total_views = V * world
+    first = rank * V
+
+    # ---- inputs -> HBM (outside the timed region) --------------------------------------------------
+    t0 = time.time()
+    pos = scene.make_positions(n, scene.BASE_SEED + 3)
+    cams_all = scene.make_cameras(total_views, W, H, convention="w2c")
+    ctx = pkg.Context(local_rank)
+    ctx.upload_positions(pos)
+    ctx.vote_begin(args.classes, first, total_views)
+    host_segs = []
+    keep_host = rank == 0 and world == 1 and args.cpu_sample > 0
+    for v in range(V):
+        seg = scene.make_segmap(H, W, args.classes, 3000 + first + v)
+        ctx.vote_view(cams_all[first + v], seg)
+        if keep_host:
+            host_segs.append(seg)
+    ctx.synchronize()
+    setup_s = time.time() - t0
+
+    shard = pkg.dist.GpuVoteShard(ctx)
+
+    def step():
+        ctx.vote_rewind()
+        if world == 1:
+            ctx.vote_finalize(to_host=False)      # fused kernel -> int32 labels in HBM
+        else:
+            pkg.dist.exchange_labels(shard, to_host=False)
+
+    def fence():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * total_views / (elapsed / args.steps)
+
+    # ---- dominant kernel: HIP-event time on the ctx stream, algorithmic bytes / time ------------------
+    kname = "vote_fused_labels" if world == 1 else "vote_fused_planes"
+    roofline = None
+    vis_frac = None
+    if rank == 0:
+        import oracle
+        sub_idx = np.random.default_rng(5).choice(n, min(n, 20_000), replace=False)
+        sub = np.ascontiguousarray(pos[sub_idx])
+        probe = range(0, V, max(1, V // 20))
+        vis = [float((oracle.project_many(sub, cams_all[first + v])[0] >= 0).mean()) for v in probe]
+        vis_frac = float(np.mean(vis))
+    if rank == 0 and not args.no_profile:
+        launches, total_ms = ctx.profile_get(kname)
+        if launches:
+            k_ms = total_ms / launches
+            n_vis = vis_frac * n * V
+            if world == 1:
+                # positions once (12 B) + one u8 seg gather per visible pair + int32 label
+                alg = 12.0 * n + 1.0 * n_vis + 4.0 * n + 192.0 * V
+            else:
+                esz = 2 if total_views > 255 else 1
+                alg = 12.0 * n + 1.0 * n_vis + 2.0 * esz * (args.classes + 1) * n + 192.0 * V
+            achieved = alg / (k_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(kname)
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "kernel_ms": round(k_ms, 4), "launches": launches, "algorithmic_bytes": int(alg),
+                        "note": "fp64-VALU/gather-latency bound kernel; see DESIGN.md §6"}
+
+    # ---- CPU baseline: the oracle (C port of the reference loop) on a bounded sample ---------------------
+    cpu = None
+    if keep_host:
+        import oracle
+        m = min(n, args.cpu_sample)
+        sub = np.ascontiguousarray(pos[:m])
+        sizes = [(W, H)] * V
+        t0 = time.perf_counter()
+        want = oracle.assign_labels(sub, cams_all[:V], host_segs, sizes, threads=0)
+        dt = time.perf_counter() - t0
+        cores = oracle.assign_labels.threads_used
+        ctx.vote_rewind()
+        labels_gpu = ctx.vote_finalize(to_host=True)
+        parity = bool(np.array_equal(labels_gpu[:m], want))
+        cpu = {"value": round(m * V / dt, 1), "unit": "Gaussian·views/s", "cores": int(cores), "kind": "port",
+               "sample": f"first {m} Gaussians x {V} views @{W}x{H} (same scene), oracle/vote_oracle.c, OpenMP",
+               "seconds": round(dt, 2), "labels_match_gpu": parity}
+
+    if rank == 0:
+        out = {
+            "metric": "Gaussian-views/sec labelled (3M Gaussians, 1080p views, majority vote)",
+            "value": round(value, 1), "unit": "Gaussian·views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n} Gaussians x {V} views/GPU @{W}x{H}, {args.classes} classes + (-1), "
+                                   f"BASELINE configs[{2 if world == 1 else 3}]",
+                       "gaussians": n, "views_per_gpu": V, "views_total": total_views, "width": W, "height": H,
+                       "classes": args.classes, "parallelism": f"views sharded x{world}",
+                       "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
+                       "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
+                       "setup_seconds": round(setup_s, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+/*
+ * gsx.h — C ABI of libgsx.so: MI355X (gfx950) Gaussian-splat majority-vote labeler + rasterizer.
+ *
+ * Plain C types only (pointers, sizes, PODs); no C++ or torch types cross this boundary.
+ * The reference (GloireLINVANI/3D_Gaussian_Splatting_Project) has no FFI: its hot path lives
+ * behind Python functions.  Each entry point names the reference lines it replaces
+ * (dls.py = deep_learning_segmentation.py, gs.js = Web_Viewer_Gaussians_Selection/gaussians_selection.js).
+ *
+ * Conventions
+ *   - every function returns GSX_OK (0) or a negative gsx_status; gsx_last_error() has the text.
+ *   - "not visible" / "no vote" are ordinary results, never errors (dls.py:73,82,306).
+ *   - host pointers are read/written during the call only; the library never keeps them.
+ *   - device pointers returned by *_device() accessors stay valid until the next gsx_vote_begin /
+ *     gsx_upload_* on the same ctx, and belong to the ctx.
+ *   - one ctx = one GPU = one HIP stream; a ctx is used from one host thread at a time.
+ *   - there is NO CPU fallback: without a gfx950 device gsx_create fails with GSX_E_HIP.
+ */
+#ifndef GSX_H
+#define GSX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSX_ABI_VERSION 1
+
+typedef enum gsx_status {
+    GSX_OK = 0,
+    GSX_E_INVALID = -1,     /* bad argument (NULL, negative size, unknown enum)            */
+    GSX_E_HIP = -2,         /* a HIP runtime call failed / no usable device               */
+    GSX_E_STATE = -3,       /* call order violated (e.g. vote_view before vote_begin)     */
+    GSX_E_RANGE = -4,       /* a seg-map label outside [-1, n_classes-1], too many views  */
+    GSX_E_UNSUPPORTED = -5, /* configuration outside what the kernels are built for       */
+    GSX_E_IO = -6           /* PLY file could not be read / written                       */
+} gsx_status;
+
+typedef struct gsx_ctx gsx_ctx;
+
+/* One entry of cameras.json (dls.py:17-22, 54-63; gs.js:81-107).  All fp64, as JSON gives. */
+typedef struct gsx_camera {
+    double fx, fy;
+    int32_t width, height;
+    double R[9]; /* "rotation", row-major 3x3 */
+    double p[3]; /* "position" */
+} gsx_camera;
+
+/* element type of a segmentation map handed to gsx_vote_view* (dls.py:124,142,158) */
+typedef enum gsx_seg_dtype {
+    GSX_SEG_I32 = 0, /* int32, values in [-1, n_classes-1]  (YOLO / Mask2Former maps)      */
+    GSX_SEG_I64 = 1, /* int64, same range                    (SegFormer argmax)             */
+    GSX_SEG_U8 = 2   /* uint8 holding label+1 (0 = label -1): the compact on-device form   */
+} gsx_seg_dtype;
+
+/* ---------------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------------- */
+int gsx_abi_version(void);
+/* device_id: HIP device ordinal of this process's GPU.  Fails (GSX_E_HIP) if the device is
+ * missing or is not gfx950. */
+int gsx_create(int device_id, gsx_ctx** out);
+void gsx_destroy(gsx_ctx* ctx);
+/* ctx may be NULL: returns the calling thread's last error raised without a ctx */
+const char* gsx_last_error(const gsx_ctx* ctx);
+/* the ctx's hipStream_t (as void*) on which every kernel of this ctx is launched */
+void* gsx_stream(gsx_ctx* ctx);
+int gsx_synchronize(gsx_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * scene upload — replaces load_gaussians (dls.py:25-40), which keeps only x,y,z
+ * ------------------------------------------------------------------------------------------- */
+/* SoA host arrays of n floats each */
+int gsx_upload_positions(gsx_ctx* ctx, int64_t n, const float* x, const float* y, const float* z);
+/* AoS rows (e.g. the vertex rows of a 3DGS PLY): float at base + i*stride_bytes + off_{x,y,z} */
+int gsx_upload_positions_strided(gsx_ctx* ctx, int64_t n, const void* base, int64_t stride_bytes,
+                                 int64_t off_x, int64_t off_y, int64_t off_z);
+int64_t gsx_num_gaussians(const gsx_ctx* ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * parity probe for project_gaussian (dls.py:43-82): one position through the device kernel.
+ * *visible = 0 where the reference returns None; then *x = *y = -1.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_project_one(gsx_ctx* ctx, const float pos[3], const gsx_camera* cam, int32_t* x, int32_t* y,
+                    int32_t* visible);
+/* batch form over the uploaded positions: x,y are host arrays of n int32 (-1 = not visible) */
+int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y);
+
+/* ---------------------------------------------------------------------------------------------
+ * majority vote — replaces the loop body and arg-max of assign_labels (dls.py:252-308)
+ *
+ *   gsx_vote_begin        gaussian_votes = {}                                   dls.py:252
+ *   gsx_vote_view*        one iteration of `for camera in cameras` whose PNG exists.  The caller
+ *                         keeps the skip of missing images (dls.py:256-259): views are numbered
+ *                         by the caller in processing order.                    dls.py:255-295
+ *   gsx_vote_finalize     arg-max, first-inserted label wins ties, -1 if never visible
+ *                                                                               dls.py:297-308
+ * Views are staged in device memory (compact u8 maps) and consumed by ONE fused kernel launch at
+ * flush/finalize time; they stay resident until the next gsx_vote_begin so that a run can be
+ * repeated (gsx_vote_rewind) without re-uploading.
+ * ------------------------------------------------------------------------------------------- */
+/* n_classes: labels are -1 .. n_classes-1 (n_classes <= 254).
+ * first_view / total_views: this ctx will receive the global view indices
+ * [first_view, first_view + k); total_views is the number of views over ALL ranks (sizes the
+ * counters: <= 65535).  Single GPU: first_view = 0, total_views = number of views (upper bound ok). */
+int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t total_views);
+/* seg: HOST pointer, seg_h x seg_w row-major.  img_w,img_h: the PIL image size (dls.py:261-263). */
+int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
+                  int32_t seg_h, int32_t img_w, int32_t img_h);
+/* same, seg is a DEVICE pointer (e.g. the segmentation model's output tensor on this GPU) */
+int gsx_vote_view_device(gsx_ctx* ctx, const gsx_camera* cam, const void* seg_dev, int32_t seg_dtype,
+                         int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h);
+int32_t gsx_vote_num_views(const gsx_ctx* ctx);
+/* forget accumulated votes but keep the staged views: the next flush/finalize votes them again */
+int gsx_vote_rewind(gsx_ctx* ctx);
+/* single-GPU end: runs the fused kernel (+ arg-max) and leaves int32 labels on the device.
+ * labels_out: host array of n int32, or NULL to skip the device-to-host copy. */
+int gsx_vote_finalize(gsx_ctx* ctx, int32_t* labels_out);
+/* device pointer of the n int32 labels written by gsx_vote_finalize / gsx_vote_labels_from_keys */
+void* gsx_vote_labels_device(gsx_ctx* ctx);
+
+/* ---- multi-GPU exchange (views sharded over ranks; one process per GPU) ----------------------
+ * rank-local:  gsx_vote_flush            fused kernel -> per-Gaussian vote histogram planes
+ * exchange 1:  all-reduce SUM (int32 words) over gsx_vote_counts_device()   [the histogram]
+ * rank-local:  gsx_vote_tiebreak_keys    per Gaussian: max-count bins -> (earliest view, bin) key
+ * exchange 2:  all-reduce MAX (int32) over gsx_vote_keys_device()           [n words]
+ * rank-local:  gsx_vote_labels_from_keys
+ * The counts plane packs 8- or 16-bit counters into int32 words so that an int32 SUM is exact
+ * (total votes per bin <= total_views, which fits the counter). */
+int gsx_vote_flush(gsx_ctx* ctx);
+void* gsx_vote_counts_device(gsx_ctx* ctx, int64_t* n_int32_words);
+int gsx_vote_tiebreak_keys(gsx_ctx* ctx);
+void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words);
+int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out);
+/* copies of the rank-local planes for tests: counts[bins][n] and first-view codes, widened to u16 */
+int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * profiling hooks (HIP events on the ctx stream around each kernel launch)
+ * ------------------------------------------------------------------------------------------- */
+int gsx_profile_enable(gsx_ctx* ctx, int on);
+int gsx_profile_reset(gsx_ctx* ctx);
+/* name: "vote_fused", "seg_pack", ...; returns launches and total milliseconds since reset */
+int gsx_profile_get(gsx_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSX_H */

@@ -147,6 +147,18 @@ int gsxo_assign_labels(const float* positions, int64_t n, const gsxo_view* views
     return used;
 }
 
+
+/* per-Gaussian vote of ONE view: out[i] = label+1 (the histogram bin) or -1 when the reference
+ * casts no vote (dls.py:276-288).  Lets the tests rebuild per-rank histogram planes. */
+void gsxo_view_bins(const float* positions, int64_t n, const gsxo_view* view, int32_t* out) {
+    double t[3];
+    cam_translation(&view->cam, t);
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t label;
+        out[i] = lookup(view, t, positions + 3 * i, &label) ? label + 1 : -1;
+    }
+}
+
 int gsxo_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

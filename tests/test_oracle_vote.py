@@ -1,0 +1,81 @@
+"""CPU: the oracle (oracle/vote_oracle.c) against the golden vectors recorded from the reference
+itself (tools/make_golden.py), plus checks that the fixtures really pin the subtle rules."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden_assign_cases, golden_project
+
+
+def test_oracle_project_matches_reference_golden():
+    pos, cams, gx, gy = golden_project()
+    for v, cam in enumerate(cams):
+        x, y = oracle.project_many(pos, cam)
+        assert np.array_equal(x, gx[v]) and np.array_equal(y, gy[v]), f"camera {v}"
+    assert (gx >= 0).sum() > 20000      # the fixture is not vacuous
+
+
+@pytest.mark.parametrize("case", golden_assign_cases(), ids=lambda c: c[0])
+def test_oracle_assign_matches_reference_golden(case):
+    name, pos, cams, segs, sizes, labels = case
+    for threads in (1, 0):
+        got = oracle.assign_labels(pos, cams, segs, sizes, threads=threads)
+        assert np.array_equal(got, labels), name
+
+
+def _votes(pos, cams, segs, sizes):
+    return np.stack([oracle.view_bins(pos, c, s, z) for c, s, z in zip(cams, segs, sizes)])     # (V, N) bin or -1
+
+
+def test_ties_fixture_pins_first_inserted_rule():
+    """Alternative tie rules must DISAGREE with the golden labels somewhere, else the fixture pins nothing."""
+    name, pos, cams, segs, sizes, labels = [c for c in golden_assign_cases() if c[0] == "ties_"][0]
+    votes = _votes(pos, cams, segs, sizes)
+    V, N = votes.shape
+    bins = 5
+    cnt = np.zeros((bins, N), int)
+    for v in range(V):
+        m = votes[v] >= 0
+        cnt[votes[v][m], np.nonzero(m)[0]] += 1
+    voted = cnt.sum(0) > 0
+    lowest = np.where(voted, cnt.argmax(0) - 1, -1)                     # lowest label among maxima
+    assert (lowest != labels).sum() > 50
+    # "label that reaches the maximum first" (online strict >) is also wrong
+    run = np.zeros((bins, N), int); best = np.full(N, -1); bestc = np.zeros(N, int)
+    for v in range(V):
+        m = np.nonzero(votes[v] >= 0)[0]
+        run[votes[v][m], m] += 1
+        c = run[votes[v][m], m]
+        upd = c > bestc[m]
+        best[m[upd]] = votes[v][m][upd] - 1; bestc[m[upd]] = c[upd]
+    assert (best != labels).sum() > 10
+    # reverse-order ">=" rule (what the HIP kernel uses) IS the reference rule
+    run[:] = 0; best[:] = -1; bestc[:] = 0
+    for v in range(V - 1, -1, -1):
+        m = np.nonzero(votes[v] >= 0)[0]
+        run[votes[v][m], m] += 1
+        c = run[votes[v][m], m]
+        upd = c >= bestc[m]
+        best[m[upd]] = votes[v][m][upd] - 1; bestc[m[upd]] = c[upd]
+    assert np.array_equal(best, labels)
+
+
+def test_edge_semantics():
+    cam = {"fx": 100.0, "fy": 100.0, "width": 200, "height": 100, "rotation": np.eye(3).tolist(), "position": [0, 0, 0]}
+    P = lambda *p: oracle.project_many(np.array([p], np.float32), cam)
+    assert P(0, 0, 1)[0][0] == 100 and P(0, 0, 1)[1][0] == 50
+    assert P(0, 0, 0)[0][0] == -1                     # z == 0 -> None
+    assert P(0, 0, -1)[0][0] == -1                    # behind
+    assert P(-1.005, 0, 1)[0][0] == -1                # x in (-1, 0) is NOT truncated to 0
+    assert P(-1.0, 0, 1)[0][0] == 0                   # x == 0.0 is inside
+    assert P(0.99999, 0, 1)[0][0] == 199
+    assert P(1.0, 0, 1)[0][0] == -1                   # x == width is outside
+    assert P(np.nan, 0, 1)[0][0] == -1 and P(np.inf, 0, 1)[0][0] == -1
+
+
+def test_numpy_shard_protocol_equals_oracle_single_process():
+    """The exchange protocol (dist.py steps 3-5) on ONE shard holding all views == the oracle."""
+    for name, pos, cams, segs, sizes, labels in golden_assign_cases():
+        sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 0, max(1, len(cams)))
+        sh.compute_keys()
+        assert np.array_equal(sh.labels_from_keys(), labels), name
