@@ -47,6 +47,7 @@ _SIGS = {
     "gsx_last_error": (C.c_char_p, [C.c_void_p]),
     "gsx_stream": (C.c_void_p, [C.c_void_p]),
     "gsx_synchronize": (C.c_int, [C.c_void_p]),
+    "gsx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "gsx_upload_positions": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_upload_positions_strided": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
                                                C.c_int64]),
@@ -69,6 +70,7 @@ _SIGS = {
     "gsx_vote_keys_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gsx_vote_labels_from_keys": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsx_profile_reset": (C.c_int, [C.c_void_p]),
     "gsx_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

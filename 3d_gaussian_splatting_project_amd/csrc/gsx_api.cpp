@@ -118,8 +118,8 @@ void gsx_destroy(gsx_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream);
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
-    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->d_views, &c->segpool, &c->stage, &c->errflag, &c->cnt, &c->fv,
-                           &c->keys, &c->labels})
+    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
+                           &c->cnt, &c->fv, &c->keys, &c->labels})
         b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -133,6 +133,21 @@ const char* gsx_last_error(const gsx_ctx* ctx) {
 void* gsx_stream(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
     return c ? (void*)c->stream : nullptr;
+}
+
+int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
+    CTX_OR_FAIL(ctx);
+    if (!name) return gsx::fail(c, GSX_E_INVALID, "set_option: name is NULL");
+    const std::string k(name);
+    if (k == "spatial_sort") c->opt_spatial_sort = value != 0;
+    else if (k == "xcd_swizzle") c->opt_xcd_swizzle = value != 0;
+    else if (k == "vote_unroll") {
+        if (value != 1 && value != 2 && value != 4 && value != 8)
+            return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 1, 2, 4 or 8");
+        c->opt_vote_unroll = (int)value;
+    } else
+        return gsx::fail(c, GSX_E_INVALID, "set_option: unknown option '%s'", name);
+    return GSX_OK;
 }
 
 int gsx_synchronize(gsx_ctx* ctx) {
@@ -167,6 +182,8 @@ int gsx_upload_positions(gsx_ctx* ctx, int64_t n, const float* x, const float* y
     GSX_HIP(c, hipMemcpyAsync(c->y.p, y, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     GSX_HIP(c, hipMemcpyAsync(c->z.p, z, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
+    c->sorted = false;
+    if (c->opt_spatial_sort) return gsx::spatial_sort_positions(c);
     return GSX_OK;
 }
 
@@ -203,8 +220,7 @@ int gsx_project_one(gsx_ctx* ctx, const float pos[3], const gsx_camera* cam, int
     hipError_t e = hipMemcpy(tmp.p, pos, 3 * sizeof(float), hipMemcpyHostToDevice);
     int rc = GSX_OK;
     if (e != hipSuccess) rc = gsx::fail(c, GSX_E_HIP, "project_one: H2D failed: %s", hipGetErrorString(e));
-    if (!rc) rc = gsx::project_all(c, cam, tmp.as<float>(), tmp.as<float>() + 1, tmp.as<float>() + 2, 1, x, y);
-    tmp.release();
+    if (!rc) rc = gsx::project_all(c, cam, tmp.as<float>(), tmp.as<float>() + 1, tmp.as<float>() + 2, 1, x, y, nullptr);
     if (!rc) *visible = (*x >= 0) ? 1 : 0;
     return rc;
 }
@@ -212,7 +228,8 @@ int gsx_project_one(gsx_ctx* ctx, const float pos[3], const gsx_camera* cam, int
 int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y) {
     CTX_OR_FAIL(ctx);
     if (!cam || !x || !y) return gsx::fail(c, GSX_E_INVALID, "project_all: NULL argument");
-    return gsx::project_all(c, cam, c->x.as<float>(), c->y.as<float>(), c->z.as<float>(), c->n, x, y);
+    return gsx::project_all(c, cam, c->x.as<float>(), c->y.as<float>(), c->z.as<float>(), c->n, x, y,
+                            c->sorted ? c->perm.as<uint32_t>() : nullptr);
 }
 
 // ---- vote ----------------------------------------------------------------------------------------
@@ -273,6 +290,30 @@ int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out) {
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
     return gsx::vote_debug_planes(c, counts_out, first_out);
+}
+
+int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || bits < 0 || bits > 32 || (n > 0 && (!keys || !values)))
+        return gsx::fail(c, GSX_E_INVALID, "debug_sort_pairs: bad arguments");
+    if (n == 0) return GSX_OK;
+    GSX_HIP(c, hipSetDevice(c->device));
+    gsx::DevBuf k0, v0, k1, v1;
+    const size_t nb = sizeof(uint32_t) * (size_t)n;
+    GSX_HIP(c, k0.ensure(nb));
+    GSX_HIP(c, v0.ensure(nb));
+    GSX_HIP(c, k1.ensure(nb));
+    GSX_HIP(c, v1.ensure(nb));
+    GSX_HIP(c, hipMemcpyAsync(k0.p, keys, nb, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(v0.p, values, nb, hipMemcpyHostToDevice, c->stream));
+    int where = 0;
+    int rc = gsx::radix_sort_pairs(c, k0.as<uint32_t>(), v0.as<uint32_t>(), k1.as<uint32_t>(), v1.as<uint32_t>(), n, bits,
+                                   &where);
+    if (rc) return rc;
+    GSX_HIP(c, hipMemcpyAsync(keys, where ? k1.p : k0.p, nb, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(values, where ? v1.p : v0.p, nb, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
 }
 
 // ---- profiling -----------------------------------------------------------------------------------

@@ -30,6 +30,21 @@ int fail(Ctx* c, int code, const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
     hipError_t ensure(size_t bytes) {  // contents are NOT preserved on growth
         if (bytes <= cap) return hipSuccess;
         if (p) (void)hipFree(p);
@@ -58,7 +73,7 @@ struct alignas(16) ViewDesc {
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
     long long seg_off;      // byte offset of this view's u8 map in the seg pool
     int seg_w, seg_h;
-    int unit_scale;  // both scales are exactly 1.0 -> int(x*1.0) == x, clamp is a no-op
+    int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
     int pad_;
 };
 
@@ -75,7 +90,15 @@ struct Ctx {
     // scene
     int64_t n = 0;
     int64_t n_pad = 0;  // n rounded up to 256: row pitch of the vote planes
-    DevBuf x, y, z;     // SoA f32 positions
+    DevBuf x, y, z;     // SoA f32 positions (Morton order when `sorted`)
+    DevBuf perm;        // u32[n]: original index of slot i (valid when `sorted`)
+    bool sorted = false;
+    DevBuf sort_hist;   // radix-sort scratch
+
+    // options (gsx_set_option)
+    int opt_spatial_sort = 1;  // Morton-order the Gaussians at upload (results do not depend on it)
+    int opt_xcd_swizzle = 1;   // consecutive logical workgroups share an XCD (its L2)
+    int opt_vote_unroll = 4;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
 
     // vote
     bool vote_begun = false;
@@ -124,7 +147,11 @@ int vote_tiebreak_keys(Ctx* c);
 int vote_labels_from_keys(Ctx* c, int32_t* labels_out);
 int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out);
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
-                int32_t* x_host, int32_t* y_host);
+                int32_t* x_host, int32_t* y_host, const uint32_t* perm);
+// sort.hip
+int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
+                     int* result_in);
+int spatial_sort_positions(Ctx* c);
 void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);
 
 }  // namespace gsx

@@ -1,0 +1,325 @@
+// sort.hip — stable LSD radix sort of (u32 key, u32 value) pairs for gfx950, 8 bits per pass.
+//
+// Used for (a) the one-off Morton ordering of the Gaussians at upload (vote locality) and
+// (b) the per-view (tile | depth16) ordering of the rasterizer, which restates the stable
+// 16-bit counting sort of the reference viewer (gaussians_selection.js:417-462).
+//
+// Per pass, three launches:
+//   radix_hist     tile (4096 keys) histograms           -> hist[digit][tile]
+//   radix_rowscan  one workgroup per digit: exclusive scan along the tiles, row total -> rowsum
+//   radix_scatter  wave-ballot multi-split: every wave ranks its 64 keys per round with 8
+//                  __ballot()s (peers = lanes holding the same digit), LDS holds the per-wave digit
+//                  counters, the scatter is stable by construction (tile, wave, round, lane order)
+// All loads are coalesced 4 B/lane; the scatter writes runs of equal digits.
+#include <hip/hip_runtime.h>
+
+#include "gsx_ctx.hpp"
+
+namespace gsx {
+
+static constexpr int kSortBlock = 256;
+static constexpr int kSortWaves = kSortBlock / 64;
+static constexpr int kSortItems = 16;                          // keys per thread
+static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per workgroup
+static constexpr int kWaveChunk = 64 * kSortItems;             // 1024 consecutive keys per wave
+
+__global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long n,
+                                                                 int shift, uint32_t* __restrict__ hist,
+                                                                 int ntiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * kSortTile;
+#pragma unroll 4
+    for (int k = 0; k < kSortItems; ++k) {
+        const long long i = base + (long long)k * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(long long)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// block d: exclusive scan of hist[d][0..ntiles) in place; rowsum[d] = total
+__global__ __launch_bounds__(kSortBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, int ntiles,
+                                                                    uint32_t* __restrict__ rowsum) {
+    __shared__ uint32_t wsum[kSortWaves];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = hist + (long long)blockIdx.x * ntiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += kSortBlock) {
+        const int t = t0 + threadIdx.x;
+        const uint32_t v = t < ntiles ? row[t] : 0u;
+        uint32_t inc = v;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = carry_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (t < ntiles) row[t] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kSortBlock - 1) carry_s = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowsum[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                    const uint32_t* __restrict__ vals_in,
+                                                                    uint32_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ vals_out, long long n,
+                                                                    int shift, const uint32_t* __restrict__ hist,
+                                                                    const uint32_t* __restrict__ rowsum, int ntiles) {
+    __shared__ uint32_t gbase[256];               // global start of this tile's run of each digit
+    __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counters, then exclusive bases
+    __shared__ uint32_t wsum[kSortWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = threadIdx.x;
+
+    // digit bases: exclusive scan of rowsum over the 256 digits + this tile's offset inside the digit
+    {
+        const uint32_t v = rowsum[d];
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) wcount[w][d] = 0;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        gbase[d] = off + inc - v + hist[(long long)d * ntiles + blockIdx.x];
+    }
+    __syncthreads();
+
+    const long long wbase_idx = (long long)blockIdx.x * kSortTile + (long long)wave * kWaveChunk;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t key[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const long long i = wbase_idx + r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? keys_in[i] : 0u;
+        const uint32_t dg = (key[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = wcount[wave][dg];
+        rank[r] = before + (uint32_t)__popcll(peers & lt);
+        // the wave runs in lockstep: every lane has read `before` before the leader's store issues
+        if (valid && (peers & lt) == 0ull) wcount[wave][dg] = before + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    {
+        uint32_t run = gbase[d];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t c = wcount[w][d];
+            wcount[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const long long i = wbase_idx + r * 64 + lane;
+        if (i < n) {
+            const uint32_t dg = (key[r] >> shift) & 255u;
+            const uint32_t pos = wcount[wave][dg] + rank[r];
+            keys_out[pos] = key[r];
+            vals_out[pos] = vals_in[i];
+        }
+    }
+}
+
+// Sorts n pairs by key bits [0, bits).  Ping-pongs between (k0,v0) and (k1,v1); *result_in is 0 or 1.
+int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
+                     int* result_in) {
+    *result_in = 0;
+    if (n <= 1 || bits <= 0) return GSX_OK;
+    const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
+    GSX_HIP(c, c->sort_hist.ensure(sizeof(uint32_t) * ((size_t)256 * ntiles + 256)));
+    uint32_t* hist = c->sort_hist.as<uint32_t>();
+    uint32_t* rowsum = hist + (size_t)256 * ntiles;
+    uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    int where = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+        {
+            ProfScope ps(c, "radix_hist");
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, shift, hist, ntiles);
+        }
+        {
+            ProfScope ps(c, "radix_rowscan");
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(kSortBlock), 0, c->stream, hist, ntiles, rowsum);
+        }
+        {
+            ProfScope ps(c, "radix_scatter");
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, shift,
+                               hist, rowsum, ntiles);
+        }
+        GSX_HIP(c, hipGetLastError());
+        std::swap(ki, ko);
+        std::swap(vi, vo);
+        where ^= 1;
+    }
+    *result_in = where;
+    return GSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Morton order of the positions (performance only: results never depend on the order)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float finite_or(float v, float alt) { return (v - v == 0.0f) ? v : alt; }
+
+__global__ __launch_bounds__(kSortBlock) void bbox_partial_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ y,
+                                                                   const float* __restrict__ z, long long n,
+                                                                   float* __restrict__ partial /*[grid][6]*/) {
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kSortBlock) {
+        const float v[3] = {x[i], y[i], z[i]};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], finite_or(v[a], 3.0e38f));
+            hi[a] = fmaxf(hi[a], finite_or(v[a], -3.0e38f));
+        }
+    }
+    __shared__ float s[kSortWaves][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], o));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], o));
+        }
+        if (lane == 0) {
+            s[wave][a] = lo[a];
+            s[wave][3 + a] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float r = s[0][threadIdx.x];
+        for (int w = 1; w < kSortWaves; ++w) r = threadIdx.x < 3 ? fminf(r, s[w][threadIdx.x]) : fmaxf(r, s[w][threadIdx.x]);
+        partial[blockIdx.x * 6 + threadIdx.x] = r;
+    }
+}
+
+__global__ void bbox_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ box) {
+    if (threadIdx.x < 6) {
+        float r = partial[threadIdx.x];
+        for (int p = 1; p < nparts; ++p) {
+            const float v = partial[p * 6 + threadIdx.x];
+            r = threadIdx.x < 3 ? fminf(r, v) : fmaxf(r, v);
+        }
+        box[threadIdx.x] = r;
+    }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    return (v | (v << 2)) & 0x09249249u;
+}
+
+__global__ __launch_bounds__(kSortBlock) void morton_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                             const float* __restrict__ z, long long n,
+                                                             const float* __restrict__ box,
+                                                             uint32_t* __restrict__ code, uint32_t* __restrict__ idx) {
+    const long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x;
+    if (i >= n) return;
+    const float v[3] = {x[i], y[i], z[i]};
+    uint32_t q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = box[3 + a] - box[a];
+        float t = ext > 0.0f ? (v[a] - box[a]) / ext * 1023.0f : 0.0f;
+        t = (t - t == 0.0f) ? fminf(fmaxf(t, 0.0f), 1023.0f) : 0.0f;  // non-finite positions sort first
+        q[a] = (uint32_t)t;
+    }
+    code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kSortBlock) void gather3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                              const float* __restrict__ z,
+                                                              const uint32_t* __restrict__ perm, long long n,
+                                                              float* __restrict__ ox, float* __restrict__ oy,
+                                                              float* __restrict__ oz) {
+    const long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = perm[i];
+    ox[i] = x[s];
+    oy[i] = y[s];
+    oz[i] = z[s];
+}
+
+// Reorders c->x/y/z along a 30-bit Morton curve; c->perm[i] = original index of sorted slot i.
+int spatial_sort_positions(Ctx* c) {
+    const long long n = c->n;
+    c->sorted = false;
+    if (n < 2) return GSX_OK;
+    const size_t nb = sizeof(uint32_t) * (size_t)n;
+    DevBuf code0, code1, idx1, box, tx, ty, tz;
+    GSX_HIP(c, code0.ensure(nb));
+    GSX_HIP(c, code1.ensure(nb));
+    GSX_HIP(c, idx1.ensure(nb));
+    GSX_HIP(c, c->perm.ensure(nb));
+    const int parts = 512;
+    GSX_HIP(c, box.ensure(sizeof(float) * (6 * parts + 6)));
+    float* partial = box.as<float>();
+    float* bb = partial + 6 * parts;
+    const unsigned grid = (unsigned)((n + kSortBlock - 1) / kSortBlock);
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(parts), dim3(kSortBlock), 0, c->stream, c->x.as<float>(), c->y.as<float>(),
+                       c->z.as<float>(), n, partial);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, c->stream, partial, parts, bb);
+    hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(kSortBlock), 0, c->stream, c->x.as<float>(), c->y.as<float>(),
+                       c->z.as<float>(), n, bb, code0.as<uint32_t>(), c->perm.as<uint32_t>());
+    GSX_HIP(c, hipGetLastError());
+    int where = 0;
+    int rc = radix_sort_pairs(c, code0.as<uint32_t>(), c->perm.as<uint32_t>(), code1.as<uint32_t>(), idx1.as<uint32_t>(), n, 30,
+                              &where);
+    if (!rc) {
+        if (where == 1) {
+            hipError_t e = hipMemcpyAsync(c->perm.p, idx1.p, nb, hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) rc = fail(c, GSX_E_HIP, "spatial sort: %s", hipGetErrorString(e));
+        }
+    }
+    if (!rc) {
+        hipError_t e = tx.ensure(sizeof(float) * n);
+        if (e == hipSuccess) e = ty.ensure(sizeof(float) * n);
+        if (e == hipSuccess) e = tz.ensure(sizeof(float) * n);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gather3_kernel, dim3(grid), dim3(kSortBlock), 0, c->stream, c->x.as<float>(), c->y.as<float>(),
+                               c->z.as<float>(), c->perm.as<uint32_t>(), n, tx.as<float>(), ty.as<float>(), tz.as<float>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, GSX_E_HIP, "spatial sort: %s", hipGetErrorString(e));
+        else {
+            std::swap(c->x, tx);
+            std::swap(c->y, ty);
+            std::swap(c->z, tz);
+            c->sorted = true;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&code0, &code1, &idx1, &box, &tx, &ty, &tz}) b->release();
+    return rc;
+}
+
+}  // namespace gsx

@@ -68,14 +68,25 @@ __device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, dou
 
 __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ z, long long n,
-                                                         const ViewDesc* __restrict__ vd, int* __restrict__ ox,
+                                                         const ViewDesc* __restrict__ vd,
+                                                         const uint32_t* __restrict__ perm, int* __restrict__ ox,
                                                          int* __restrict__ oy) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int xi, yi;
     const bool vis = project(*vd, (double)x[i], (double)y[i], (double)z[i], xi, yi);
-    ox[i] = vis ? xi : -1;
-    oy[i] = vis ? yi : -1;
+    const long long o = perm ? (long long)perm[i] : i;  // back to the caller's order
+    ox[o] = vis ? xi : -1;
+    oy[o] = vis ? yi : -1;
+}
+
+// Workgroups b and b+8 run on the same XCD (round-robin dispatch; a speed heuristic, never needed for
+// correctness).  Map them to consecutive logical blocks so that one XCD's L2 serves one contiguous
+// stretch of the Morton curve = one compact patch of every segmentation map.  Bijective for any grid.
+__device__ __forceinline__ unsigned logical_block(unsigned b, unsigned nwg, int swizzle) {
+    if (!swizzle) return b;
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -128,7 +139,9 @@ struct FusedParams {
     int nviews;             // <= kMaxBatch
     const uint8_t* pool;
     int bins;
-    int stride_dw;  // LDS row stride in dwords (odd)
+    int stride_dw;         // LDS row stride in dwords (odd)
+    int xcd_swizzle;       // see logical_block()
+    const uint32_t* perm;  // sorted slot -> caller's index, or nullptr
 };
 
 template <int U>
@@ -138,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
     for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
     uint8_t* h = reinterpret_cast<uint8_t*>(row);
 
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     const bool valid = i < p.n;
     // lanes past the end carry NaN: every comparison in project() fails, they never vote
     const double X = valid ? (double)p.x[i] : __builtin_nan("");
@@ -171,7 +184,10 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
             }
         }
     }
-    if (valid) labels[i] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
+    if (valid) {
+        const long long o = p.perm ? (long long)p.perm[i] : i;
+        labels[o] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -190,7 +206,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
     for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;
     uint16_t* h = reinterpret_cast<uint16_t*>(row);
 
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     const bool valid = i < p.n;
     const double X = valid ? (double)p.x[i] : __builtin_nan("");
     const double Y = valid ? (double)p.y[i] : 0.0;
@@ -259,11 +275,12 @@ __global__ __launch_bounds__(kBlock) void vote_keys_kernel(const PT* __restrict_
 }
 
 __global__ __launch_bounds__(kBlock) void vote_labels_kernel(const int* __restrict__ keys, long long n,
+                                                             const uint32_t* __restrict__ perm,
                                                              int* __restrict__ labels) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int k = keys[i];
-    labels[i] = k ? (k & 0xff) - 1 : -1;
+    labels[perm ? (long long)perm[i] : i] = k ? (k & 0xff) - 1 : -1;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -288,13 +305,14 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.hscale = (double)seg_h / (double)img_h;
     vd.seg_w = seg_w;
     vd.seg_h = seg_h;
-    vd.unit_scale = (vd.wscale == 1.0 && vd.hscale == 1.0) ? 1 : 0;
+    // int(x*1.0) == x; the clamp (dls.py:285-286) is a no-op only if the camera frame fits the map
+    vd.unit_scale = (vd.wscale == 1.0 && vd.hscale == 1.0 && cam->width <= seg_w && cam->height <= seg_h) ? 1 : 0;
 }
 
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
-                int32_t* x_host, int32_t* y_host) {
+                int32_t* x_host, int32_t* y_host, const uint32_t* perm) {
     if (n <= 0) return GSX_OK;
     GSX_HIP(c, hipSetDevice(c->device));
     ViewDesc vd;
@@ -308,7 +326,7 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
         hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
-                           dvd.as<ViewDesc>(), ox.as<int>(), oy.as<int>());
+                           dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(x_host, ox.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream);
@@ -499,6 +517,8 @@ int vote_flush(Ctx* c) {
     p.n = c->n;
     p.pool = c->segpool.as<uint8_t>();
     p.bins = c->bins;
+    p.xcd_swizzle = c->opt_xcd_swizzle;
+    p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
     p.stride_dw = odd_dwords(c->bins * 2);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
     while (c->n_flushed < nv) {
@@ -564,7 +584,7 @@ int vote_labels_from_keys(Ctx* c, int32_t* labels_out) {
     if (c->n > 0) {
         ProfScope ps(c, "vote_labels");
         hipLaunchKernelGGL(vote_labels_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->keys.as<int>(),
-                           (long long)c->n, c->labels.as<int>());
+                           (long long)c->n, c->sorted ? c->perm.as<uint32_t>() : nullptr, c->labels.as<int>());
         GSX_HIP(c, hipGetLastError());
     }
     return labels_to_host(c, labels_out);
@@ -589,9 +609,14 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             p.nviews = nv;
             p.pool = c->segpool.as<uint8_t>();
             p.bins = c->bins;
+            p.xcd_swizzle = c->opt_xcd_swizzle;
+            p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
             p.stride_dw = odd_dwords(c->bins);
             const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-            auto k = vote_fused_labels_kernel<kUnroll>;
+            auto k = c->opt_vote_unroll == 1   ? vote_fused_labels_kernel<1>
+                     : c->opt_vote_unroll == 2 ? vote_fused_labels_kernel<2>
+                     : c->opt_vote_unroll == 8 ? vote_fused_labels_kernel<8>
+                                               : vote_fused_labels_kernel<4>;
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->labels.as<int>());
@@ -612,6 +637,11 @@ int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
     const size_t esz = c->wide ? 2 : 1;
     const size_t elems = (size_t)c->bins * (size_t)c->n_pad;
     std::vector<uint8_t> tmp(elems * esz);
+    std::vector<uint32_t> perm;
+    if (c->sorted && c->n > 0) {
+        perm.resize((size_t)c->n);
+        GSX_HIP(c, hipMemcpy(perm.data(), c->perm.p, sizeof(uint32_t) * (size_t)c->n, hipMemcpyDeviceToHost));
+    }
     for (int which = 0; which < 2; ++which) {
         GSX_HIP(c, hipMemcpyAsync(tmp.data(), which ? c->fv.p : c->cnt.p, elems * esz, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
@@ -619,7 +649,7 @@ int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
         for (int b = 0; b < c->bins; ++b)
             for (int64_t i = 0; i < c->n; ++i) {
                 const size_t at = (size_t)b * c->n_pad + i;
-                out[(size_t)b * c->n + i] = c->wide ? reinterpret_cast<uint16_t*>(tmp.data())[at] : tmp[at];
+                out[(size_t)b * c->n + (perm.empty() ? (size_t)i : (size_t)perm[i])] = c->wide ? reinterpret_cast<uint16_t*>(tmp.data())[at] : tmp[at];
             }
     }
     return GSX_OK;

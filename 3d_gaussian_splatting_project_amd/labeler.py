@@ -50,6 +50,10 @@ class Context:
     def __exit__(self, *a):
         self.close()
 
+    def set_option(self, name, value):
+        """Tuning knobs of gsx_set_option (spatial_sort, xcd_swizzle, vote_unroll); never change results."""
+        check(self._lib.gsx_set_option(self.h, name.encode(), int(value)), self.h)
+
     # -- scene ---------------------------------------------------------------------------------
     def upload_positions(self, positions):
         """positions: (N,3) float array, or a structured array with a 'position' field
@@ -153,6 +157,13 @@ class Context:
         fv = np.empty((bins, self.n), np.uint16)
         check(self._lib.gsx_vote_debug_planes(self.h, cnt.ctypes.data, fv.ctypes.data), self.h)
         return cnt, fv
+
+    def sort_pairs(self, keys, values, bits=32):
+        """Stable GPU radix sort by key bits [0, bits) (test hook, gsx_debug_sort_pairs)."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+        v = np.ascontiguousarray(values, dtype=np.uint32).copy()
+        check(self._lib.gsx_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, len(k), bits), self.h)
+        return k, v
 
     def synchronize(self):
         check(self._lib.gsx_synchronize(self.h), self.h)

@@ -39,7 +39,11 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--classes", type=int, default=150)
-    ap.add_argument("--cpu-sample", type=int, default=400_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="cap on CPU-baseline OpenMP threads (box CPU share)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--order", default="input", choices=["input", "morton_host"],
+                    help="experiment: pre-sort the Gaussians on the host before upload")
+    ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     return ap.parse_args()
 
@@ -69,8 +73,20 @@ def main():
     # ---- inputs -> HBM (outside the timed region) --------------------------------------------------
     t0 = time.time()
     pos = scene.make_positions(n, scene.BASE_SEED + 3)
+    if args.order == "morton_host":
+        q = ((pos - pos.min(0)) / (pos.max(0) - pos.min(0)) * 1023.0).astype(np.uint32)
+        def spread(v):
+            v = (v | (v << 16)) & 0x030000FF
+            v = (v | (v << 8)) & 0x0300F00F
+            v = (v | (v << 4)) & 0x030C30C3
+            return (v | (v << 2)) & 0x09249249
+        code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+        pos = np.ascontiguousarray(pos[np.argsort(code, kind="stable")])
     cams_all = scene.make_cameras(total_views, W, H, convention="w2c")
     ctx = pkg.Context(local_rank)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     ctx.upload_positions(pos)
     ctx.vote_begin(args.classes, first, total_views)
     host_segs = []
@@ -159,7 +175,8 @@ def main():
         sub = np.ascontiguousarray(pos[:m])
         sizes = [(W, H)] * V
         t0 = time.perf_counter()
-        want = oracle.assign_labels(sub, cams_all[:V], host_segs, sizes, threads=0)
+        threads = min(oracle.max_threads(), len(os.sched_getaffinity(0)), args.cpu_threads)
+        want = oracle.assign_labels(sub, cams_all[:V], host_segs, sizes, threads=threads)
         dt = time.perf_counter() - t0
         cores = oracle.assign_labels.threads_used
         ctx.vote_rewind()

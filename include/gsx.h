@@ -66,6 +66,12 @@ const char* gsx_last_error(const gsx_ctx* ctx);
 /* the ctx's hipStream_t (as void*) on which every kernel of this ctx is launched */
 void* gsx_stream(gsx_ctx* ctx);
 int gsx_synchronize(gsx_ctx* ctx);
+/* tuning knobs; none of them changes any result.
+ *   "spatial_sort" (default 1)  Morton-order the Gaussians on the GPU at upload: a wave's 64 Gaussians
+ *                               then project to neighbouring pixels (seg-map gathers hit few lines)
+ *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
+ *   "vote_unroll"  (default 4)  views whose seg-map gathers are in flight together: 1, 2, 4, 8 */
+int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
 
 /* ---------------------------------------------------------------------------------------------
  * scene upload — replaces load_gaussians (dls.py:25-40), which keeps only x,y,z
@@ -134,6 +140,13 @@ void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words);
 int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out);
 /* copies of the rank-local planes for tests: counts[bins][n] and first-view codes, widened to u16 */
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * test hook: the library's stable LSD radix sort of (u32 key, u32 value) pairs by key bits
+ * [0, bits) — the primitive behind the Morton ordering and the rasterizer's (tile | depth16) order,
+ * which restates the stable counting sort of gs.js:443-457.  Host arrays, sorted in place.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits);
 
 /* ---------------------------------------------------------------------------------------------
  * profiling hooks (HIP events on the ctx stream around each kernel launch)

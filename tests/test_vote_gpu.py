@@ -54,6 +54,44 @@ def test_project_large_random_vs_oracle(ctx):
         assert (ox >= 0).mean() > 0.3
 
 
+# ---- radix sort + spatial order ---------------------------------------------------------------------
+@pytest.mark.parametrize("n,bits", [(1, 32), (63, 8), (4096, 16), (4097, 32), (100_003, 30), (1_000_000, 29)])
+def test_radix_sort_is_stable_and_correct(ctx, n, bits):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32)
+    if n == 4096:
+        keys[:] = keys % 7                     # heavy duplicates: stability matters
+    vals = np.arange(n, dtype=np.uint32)
+    k, v = ctx.sort_pairs(keys, vals, bits)
+    mask = np.uint32((1 << bits) - 1) if bits < 32 else np.uint32(0xFFFFFFFF)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(v, vals[order]) and np.array_equal(k, keys[order])
+
+
+def test_results_do_not_depend_on_tuning_options(gsx):
+    n = 70_001
+    pos, cams, segs = scene.make_scene(n, 9, 480, 270, config_id=12, convention="w2c")
+    sizes = [(480, 270)] * 9
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 1}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
+                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4}):
+        with gsx.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+            assert np.array_equal(got, want), opts
+            c.vote_rewind()
+            c.vote_flush()
+            c.vote_tiebreak_keys()
+            assert np.array_equal(c.vote_labels_from_keys(), want), opts
+            x, y = c.project_all(cams[0])
+            ox, oy = oracle.project_many(pos, cams[0])
+            assert np.array_equal(x, ox) and np.array_equal(y, oy)
+            sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 0, 9)
+            cnt, fv = c.debug_planes(151)
+            assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
+
+
 # ---- assign_labels ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("case", golden_assign_cases(), ids=lambda c: c[0])
 def test_labels_match_reference_golden(ctx, case):
@@ -104,7 +142,7 @@ def test_wide_counters_and_multi_batch(ctx):
     cnt, fv = ctx.debug_planes(5)
     sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 4, 0, V)
     assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
-    assert cnt.max() > 150
+    assert cnt.max() > 60           # counts beyond one 255-view batch's share were accumulated
 
 
 def test_view_sharding_exchange_on_one_gpu(gsx, ctx):
