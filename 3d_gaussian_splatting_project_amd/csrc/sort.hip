@@ -13,6 +13,8 @@
 // All loads are coalesced 4 B/lane; the scatter writes runs of equal digits.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "gsx_ctx.hpp"
 
 namespace gsx {
@@ -24,8 +26,8 @@ static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per 
 static constexpr int kWaveChunk = 64 * kSortItems;             // 1024 consecutive keys per wave
 
 __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long n,
-                                                                 int shift, uint32_t* __restrict__ hist,
-                                                                 int ntiles) {
+                                                                 int shift, uint32_t mask,
+                                                                 uint32_t* __restrict__ hist, int ntiles) {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* 
 #pragma unroll 4
     for (int k = 0; k < kSortItems; ++k) {
         const long long i = base + (long long)k * kSortBlock + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
     hist[(long long)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out, long long n,
-                                                                    int shift, const uint32_t* __restrict__ hist,
+                                                                    int shift, uint32_t mask,
+                                                                    const uint32_t* __restrict__ hist,
                                                                     const uint32_t* __restrict__ rowsum, int ntiles) {
     __shared__ uint32_t gbase[256];               // global start of this tile's run of each digit
     __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counters, then exclusive bases
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         const long long i = wbase_idx + r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? keys_in[i] : 0u;
-        const uint32_t dg = (key[r] >> shift) & 255u;
+        const uint32_t dg = (key[r] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     for (int r = 0; r < kSortItems; ++r) {
         const long long i = wbase_idx + r * 64 + lane;
         if (i < n) {
-            const uint32_t dg = (key[r] >> shift) & 255u;
+            const uint32_t dg = (key[r] >> shift) & mask;
             const uint32_t pos = wcount[wave][dg] + rank[r];
             keys_out[pos] = key[r];
             vals_out[pos] = vals_in[i];
@@ -156,9 +159,10 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     int where = 0;
     for (int shift = 0; shift < bits; shift += 8) {
+        const uint32_t mask = (1u << std::min(8, bits - shift)) - 1u;  // key bits >= `bits` never take part
         {
             ProfScope ps(c, "radix_hist");
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, shift, hist, ntiles);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, shift, mask, hist, ntiles);
         }
         {
             ProfScope ps(c, "radix_rowscan");
@@ -167,7 +171,7 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
         {
             ProfScope ps(c, "radix_scatter");
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, shift,
-                               hist, rowsum, ntiles);
+                               mask, hist, rowsum, ntiles);
         }
         GSX_HIP(c, hipGetLastError());
         std::swap(ki, ko);
