@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--classes", type=int, default=150)
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on CPU-baseline OpenMP threads (box CPU share)")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--order", default="input", choices=["input", "morton_host"],
                     help="experiment: pre-sort the Gaussians on the host before upload")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")

@@ -153,26 +153,25 @@ def test_view_sharding_exchange_on_one_gpu(gsx, ctx):
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     with gsx.Context(0) as other:
         ranks = [(ctx, 0, 6), (other, 6, 10)]
-        planes = []
+        import torch
+        counts = []
         for c, lo, hi in ranks:
             run_gpu(c, pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], n_classes=12, first=lo, total=V).vote_flush()
-            planes.append(c.debug_planes(13))
-        total = planes[0][0].astype(np.int64) + planes[1][0]
-        assert total.max() <= V
-        import torch
+            ptr, words = c.counts_device()
+            c.synchronize()
+            counts.append(gsx.dist.device_words_tensor(ptr, words, 0))
+        total = counts[0] + counts[1]          # == all_reduce(SUM) over the int32-packed u8 counters
+        for t in counts:
+            t.copy_(total)
+        torch.cuda.synchronize()
+        assert int(total.view(torch.uint8).max()) <= V
         keys = []
         for c, lo, hi in ranks:
-            ptr, words = c.counts_device()
-            t = gsx.dist.device_words_tensor(ptr, words, 0)
-            host = np.zeros((13, c.n + (-c.n) % 256), np.uint8)
-            host[:, :n] = total
-            t.copy_(torch.from_numpy(host.reshape(-1).view(np.int32)))     # "all-reduced" counts
-            torch.cuda.synchronize()
             c.vote_tiebreak_keys()
             kptr, kwords = c.keys_device()
             c.synchronize()
             keys.append(gsx.dist.device_words_tensor(kptr, kwords, 0))
-        kmax = torch.maximum(keys[0], keys[1])
+        kmax = torch.maximum(keys[0], keys[1])  # == all_reduce(MAX)
         for k in keys:
             k.copy_(kmax)
         torch.cuda.synchronize()
