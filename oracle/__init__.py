@@ -152,3 +152,127 @@ class NumpyVoteShard:
         k = self.keys[:self.n]
         self.labels = np.where(k != 0, (k & 0xff) - 1, -1).astype(np.int32)
         return self.labels
+
+
+# ---- viewer path (oracle/render_oracle.c) ---------------------------------------------------------
+class VertexOut(C.Structure):
+    _fields_ = [("drawn", C.c_int32), ("cx", C.c_float), ("cy", C.c_float), ("major", C.c_float * 2),
+                ("minor", C.c_float * 2), ("color", C.c_float * 4), ("fade", C.c_float)]
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def pack_splats(xyz, scale, rot, opacity, f_dc, rgb=None):
+    """processPlyBuffer: -> (buffer (n,32) uint8 in importance order, order (n,) uint32)."""
+    xyz, scale, rot, opacity, f_dc = map(_f32, (xyz, scale, rot, opacity, f_dc))
+    n = len(xyz)
+    buf = np.zeros((n, 32), np.uint8)
+    order = np.zeros(n, np.uint32)
+    rgb8 = None if rgb is None else np.ascontiguousarray(rgb, dtype=np.uint8)
+    f = lib().gsxo_pack_splats
+    f.restype = None
+    f.argtypes = [C.c_int64] + [C.c_void_p] * 8
+    f(n, _ptr(xyz), _ptr(scale), _ptr(rot), _ptr(opacity), _ptr(f_dc), _ptr(rgb8), buf.ctypes.data, order.ctypes.data)
+    return buf, order
+
+
+def texture(buffer, labels=None):
+    """generateTexture: -> texdata (n*8,) uint32."""
+    buffer = np.ascontiguousarray(buffer, dtype=np.uint8)
+    n = len(buffer)
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+    tex = np.zeros(8 * n, np.uint32)
+    f = lib().gsxo_texture
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(n, buffer.ctypes.data, _ptr(lab), tex.ctypes.data)
+    return tex
+
+
+def view_matrix(cam):
+    R = np.ascontiguousarray(cam["rotation"], dtype=np.float64).reshape(9)
+    p = np.ascontiguousarray(cam["position"], dtype=np.float64)
+    out = np.zeros(16)
+    f = lib().gsxo_view_matrix
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(R.ctypes.data, p.ctypes.data, out.ctypes.data)
+    return out
+
+
+def proj_matrix(fx, fy, width, height):
+    out = np.zeros(16)
+    f = lib().gsxo_proj_matrix
+    f.restype = None
+    f.argtypes = [C.c_double] * 4 + [C.c_void_p]
+    f(float(fx), float(fy), float(width), float(height), out.ctypes.data)
+    return out
+
+
+def multiply4(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros(16)
+    f = lib().gsxo_multiply4
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3
+    f(a.ctypes.data, b.ctypes.data, out.ctypes.data)
+    return out
+
+
+def depth_order(buffer, viewproj):
+    """runSort: -> (depth_index (n,) uint32 with the JS's unwritten slots = 0, dropped count)."""
+    buffer = np.ascontiguousarray(buffer, dtype=np.uint8)
+    vp = np.ascontiguousarray(viewproj, dtype=np.float64)
+    n = len(buffer)
+    di = np.zeros(n, np.uint32)
+    f = lib().gsxo_depth_order
+    f.restype = C.c_int64
+    f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+    dropped = f(n, buffer.ctypes.data, vp.ctypes.data, di.ctypes.data)
+    return di, int(dropped)
+
+
+def vertex(texel8, view, proj, fx, fy, W, H):
+    t = np.ascontiguousarray(texel8, dtype=np.uint32)
+    v = np.ascontiguousarray(view, dtype=np.float32)
+    p = np.ascontiguousarray(proj, dtype=np.float32)
+    o = VertexOut()
+    f = lib().gsxo_vertex
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    f(t.ctypes.data, v.ctypes.data, p.ctypes.data, fx, fy, W, H, C.addressof(o))
+    return o
+
+
+def render_view(texdata, depth_index, cam, W, H, override_color=None):
+    """Fragment shader + blend for one cameras.json-style camera at W x H -> (H, W, 4) float32."""
+    tex = np.ascontiguousarray(texdata, dtype=np.uint32)
+    di = np.ascontiguousarray(depth_index, dtype=np.uint32)
+    n = len(di)
+    view = view_matrix(cam)
+    proj = proj_matrix(cam["fx"], cam["fy"], W, H)
+    oc = _f32(override_color)
+    out = np.zeros((H, W, 4), np.float32)
+    f = lib().gsxo_render_view
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int32, C.c_int32,
+                  C.c_void_p, C.c_void_p]
+    f(n, tex.ctypes.data, di.ctypes.data, view.ctypes.data, proj.ctypes.data, float(cam["fx"]), float(cam["fy"]), W, H,
+      _ptr(oc), out.ctypes.data)
+    return out
+
+
+def render_scene(xyz, scale, rot, opacity, f_dc, cam, W, H, labels=None):
+    """Whole viewer path for one camera: pack -> texture -> sort -> rasterise."""
+    buf, order = pack_splats(xyz, scale, rot, opacity, f_dc)
+    tex = texture(buf, None if labels is None else np.asarray(labels)[order])
+    vp = multiply4(proj_matrix(cam["fx"], cam["fy"], W, H), view_matrix(cam))
+    di, _ = depth_order(buf, vp)
+    return render_view(tex, di, cam, W, H)
