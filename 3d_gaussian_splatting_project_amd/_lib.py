@@ -70,6 +70,12 @@ _SIGS = {
     "gsx_vote_keys_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gsx_vote_labels_from_keys": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsx_upload_splats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6),
+    "gsx_num_splats": (C.c_int64, [C.c_void_p]),
+    "gsx_render_view": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_void_p]),
+    "gsx_render_image_device": (C.c_void_p, [C.c_void_p]),
+    "gsx_render_num_pairs": (C.c_int64, [C.c_void_p]),
+    "gsx_render_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsx_profile_reset": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,95 @@
+// blend.hip — fragment shader + blend unit of the reference viewer as a tile kernel for gfx950.
+//
+// Restates gaussians_selection.js:782-799 (A = -|vPosition|^2, discard A < -4, B = exp(A) * alpha,
+// premultiplied colour) and the blend state of gs.js:1036-1038 (dst += (1 - dst.a) * src, front to
+// back) for one 16x16-pixel tile per workgroup.  The tile's depth-ordered splat list is staged
+// through LDS 256 records at a time (one coalesced gather per thread), then every pixel walks the
+// staged records with broadcast LDS reads.  Compiled with -ffp-contract=off: the operations that
+// decide `discard` round exactly like the oracle's; the accumulation uses explicit fmaf.
+#include <hip/hip_runtime.h>
+
+#include "gsx_ctx.hpp"
+
+namespace gsx {
+
+static constexpr int kTile = 16;
+static constexpr int kBlendThreads = kTile * kTile;
+
+struct Accum {
+    float r, g, b, a;
+};
+
+__device__ __forceinline__ void blend_one(Accum& acc, float fxp, float fyp, const float4 r0, const float4 r1,
+                                          const float2 r2) {
+    const float dx = fxp - r0.x;
+    const float dy = fyp - r0.y;
+    const float vx = dx * r0.z + dy * r0.w;  // interpolated vPosition (see oracle/render_oracle.c gsxo_vertex)
+    const float vy = dx * r1.x + dy * r1.y;
+    const float A = -(vx * vx + vy * vy);
+    if (!(A < -4.0f)) {  // `if (A < -4.0) discard;`
+        const float B = __expf(A) * r2.y;
+        const float om = 1.0f - acc.a;  // ONE_MINUS_DST_ALPHA, ONE
+        acc.r = __builtin_fmaf(om, B * r1.z, acc.r);
+        acc.g = __builtin_fmaf(om, B * r1.w, acc.g);
+        acc.b = __builtin_fmaf(om, B * r2.x, acc.b);
+        acc.a = __builtin_fmaf(om, B, acc.a);
+    }
+}
+
+__global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ vals,
+                                                              const float4* __restrict__ rec0,
+                                                              const float4* __restrict__ rec1,
+                                                              const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                              const int* __restrict__ dropped, long long n,
+                                                              float4* __restrict__ image) {
+    __shared__ float4 s0[kBlendThreads];
+    __shared__ float4 s1[kBlendThreads];
+    __shared__ float2 s2[kBlendThreads];
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (threadIdx.x & (kTile - 1));
+    const int py = ty * kTile + (threadIdx.x >> 4);
+    const bool inside = px < W && py < H;
+    const float fxp = (float)px + 0.5f;               // pixel centre, GL window coordinates
+    const float fyp = (float)H - ((float)py + 0.5f);  // window y is up; image row py counts from the top
+    Accum acc{0.f, 0.f, 0.f, 0.f};                    // gl.clear to (0,0,0,0), gs.js:1608
+    const int2 range = ranges[tile];
+    for (int base = range.x; base < range.y; base += kBlendThreads) {
+        const int cnt = min(kBlendThreads, range.y - base);
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const uint32_t id = vals[base + threadIdx.x];
+            s0[threadIdx.x] = rec0[id];
+            s1[threadIdx.x] = rec1[id];
+            s2[threadIdx.x] = rec2[id];
+        }
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) blend_one(acc, fxp, fyp, s0[k], s1[k], s2[k]);
+        // every further fragment is weighted by (1 - dst.a): once that is < 1e-5 on the whole tile the
+        // rest of the list changes no channel by more than 1e-5 (the parity tolerance is 1e-4)
+        if (__syncthreads_and(!inside || acc.a > 1.0f - 1.0e-5f)) break;
+    }
+    // runSort leaves the slots of the splats it drops (bucket 65536) at 0: splat 0 is drawn again,
+    // last, once per dropped splat (gs.js:453-457 + 1076-1077, 1609)
+    const int nd = n > 0 ? *dropped : 0;
+    if (nd > 0) {
+        const float4 r0 = rec0[0];
+        const float4 r1 = rec1[0];
+        const float2 r2 = rec2[0];
+        for (int k = 0; k < nd; ++k) blend_one(acc, fxp, fyp, r0, r1, r2);
+    }
+    if (inside) image[(size_t)py * W + px] = make_float4(acc.r, acc.g, acc.b, acc.a);
+}
+
+int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev) {
+    const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
+    ProfScope ps(c, "render_blend");
+    hipLaunchKernelGGL(blend_kernel, dim3(tiles_x * tiles_y), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), vals,
+                       c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                       (long long)c->rn, c->r_image.as<float4>());
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+}  // namespace gsx

@@ -119,7 +119,9 @@ void gsx_destroy(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
-                           &c->cnt, &c->fv, &c->keys, &c->labels})
+                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_image,
+                           &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
+                           &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1})
         b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -290,6 +292,34 @@ int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out) {
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
     return gsx::vote_debug_planes(c, counts_out, first_out);
+}
+
+// ---- rasterizer -----------------------------------------------------------------------------------
+int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* scale, const float* rot,
+                      const float* opacity, const float* f_dc, const int32_t* labels) {
+    CTX_OR_FAIL(ctx);
+    return gsx::upload_splats(c, n, xyz, scale, rot, opacity, f_dc, labels);
+}
+int64_t gsx_num_splats(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c ? c->rn : 0;
+}
+int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::render_view(c, cam, width, height, rgba_out);
+}
+void* gsx_render_image_device(gsx_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return c ? c->r_image.p : nullptr;
+}
+int64_t gsx_render_num_pairs(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c ? (int64_t)c->r_P : 0;
+}
+int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uint32_t* texdata_out,
+                     uint32_t* bucket_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::render_debug(c, buffer_out, order_out, texdata_out, bucket_out);
 }
 
 int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits) {

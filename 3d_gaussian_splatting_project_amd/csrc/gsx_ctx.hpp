@@ -119,6 +119,19 @@ struct Ctx {
     DevBuf keys, labels;        // [n_pad] int32
     bool labels_valid = false;
 
+    // rasterizer (render.hip / blend.hip)
+    int64_t rn = 0;                      // splats uploaded
+    DevBuf r_order, r_buffer, r_tex;     // importance permutation, .splat rows, texel pairs
+    DevBuf r_sh;                         // per-view SH colour (n x 3 f32)
+    bool r_sh_valid = false;
+    DevBuf r_image;                      // float4[H][W] of the last view
+    int r_W = 0, r_H = 0;
+    DevBuf r_ranges, r_small, r_scan;
+    DevBuf r_depth, r_bucket, r_rect, r_count, r_offset, r_rec0, r_rec1, r_rec2;
+    DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
+    int r_sorted_in = 0;
+    uint32_t r_P = 0;                    // (tile, splat) pairs of the last view
+
     // profiling
     bool prof_on = false;
     std::vector<std::string> prof_names;
@@ -152,6 +165,11 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
 int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
                      int* result_in);
 int spatial_sort_positions(Ctx* c);
+// render.hip
+int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const float* rot, const float* opacity,
+                  const float* f_dc, const int32_t* labels);
+int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out);
+int render_debug(Ctx* c, uint8_t* buffer_out, uint32_t* order_out, uint32_t* tex_out, uint32_t* bucket_out);
 void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);
 
 }  // namespace gsx

@@ -1,0 +1,619 @@
+// render.hip — tile-based forward rasterizer for gfx950, bit-faithful to the reference viewer's data path.
+//
+// Restates Web_Viewer_Gaussians_Selection/gaussians_selection.js ("gs.js"):
+//   splat_importance / splat_pack   processPlyBuffer   gs.js:513-582  (fp64 like JS numbers)
+//                                   generateTexture    gs.js:301-354  (4*Sigma as truncated fp16)
+//   depth_kernel / preprocess       runSort            gs.js:432-447  (depth int, 16-bit bucket)
+//                                   vertex shader      gs.js:696-750  (fp32, no contraction)
+//   bin / sort / ranges             the global stable counting sort (gs.js:450-457) becomes a stable
+//                                   radix sort of (tile << 17 | bucket) keys: per tile the same order
+//   blend.hip                       fragment shader + blend unit gs.js:782-799, 1036-1038
+// This TU is compiled with -ffp-contract=off: JS never fuses, and the vertex stage must produce
+// bit-identical axes to the oracle so that the fragment `discard` (A < -4) decides identically.
+//
+// HBM layout
+//   tex        uint4[2n]   the viewer's RGBA32UI texel pairs: [x y z label][h01 h23 h45 rgba8], importance order
+//   buffer     u8[32n]     the viewer's .splat rows (pos, exp(scale), rgba8, quat8)
+//   rec0/1/2   float4,float4,float2 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a)
+//   keys/vals  u32[P]      (tile << 17 | bucket, splat) pairs, P = sum of tiles touched
+//   ranges     int2[tiles] [start, end) into the sorted pairs
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "gsx_ctx.hpp"
+
+namespace gsx {
+
+static constexpr int kRB = 256;
+
+// ---- JavaScript number semantics -----------------------------------------------------------------
+__device__ __forceinline__ unsigned js_u8clamp(double x) {  // Uint8ClampedArray store
+    if (!(x > 0.0)) return 0u;
+    if (x >= 255.0) return 255u;
+    const double f = floor(x);
+    if (f + 0.5 < x) return (unsigned)(f + 1.0);
+    if (x < f + 0.5) return (unsigned)f;
+    return (unsigned)(fmod(f, 2.0) == 0.0 ? f : f + 1.0);
+}
+
+__device__ __forceinline__ int js_toint32(double x) {  // `x | 0`
+    if (!(fabs(x) <= 1.7976931348623157e308)) return 0;  // NaN, +-Infinity
+    const double t = trunc(x);
+    if (t >= -2147483648.0 && t <= 2147483647.0) return (int)t;
+    double m = fmod(t, 4294967296.0);
+    if (m < 0) m += 4294967296.0;
+    return (int)(unsigned)m;
+}
+
+__device__ __forceinline__ unsigned js_float_to_half(double v) {  // gs.js:248-275
+    const float fl = (float)v;
+    const int f = __float_as_int(fl);
+    const int sign = (f >> 31) & 0x0001;
+    const int exp = (f >> 23) & 0x00ff;
+    int frac = f & 0x007fffff;
+    int newExp;
+    if (exp == 0) {
+        newExp = 0;
+    } else if (exp < 113) {
+        newExp = 0;
+        frac |= 0x00800000;
+        frac = frac >> ((113 - exp) & 31);  // JS shift counts are taken mod 32
+        if (frac & 0x01000000) {
+            newExp = 1;
+            frac = 0;
+        }
+    } else if (exp < 142) {
+        newExp = exp - 112;
+    } else {
+        newExp = 31;
+        frac = 0;
+    }
+    return (unsigned)((sign << 15) | (newExp << 10) | (frac >> 13));
+}
+
+__device__ __forceinline__ float half_to_float(unsigned h) {  // unpackHalf2x16: exact
+    const unsigned s = (h >> 15) & 1u, e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = (float)m * 5.9604644775390625e-08f;  // 2^-24
+    else if (e == 31) v = m ? __int_as_float(0x7fc00000) : __int_as_float(0x7f800000);
+    else v = __int_as_float((int)(((e + 112u) << 23) | (m << 13)));
+    return s ? -v : v;
+}
+
+// ---- pack: processPlyBuffer + generateTexture --------------------------------------------------------
+// importance (gs.js:520-522) as a sort key: ascending ~bits == descending float (values are >= 0)
+__global__ __launch_bounds__(kRB) void splat_importance_kernel(const float* __restrict__ scale,
+                                                                const float* __restrict__ opacity, long long n,
+                                                                uint32_t* __restrict__ key, uint32_t* __restrict__ idx) {
+    const long long r = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (r >= n) return;
+    const double size = exp((double)scale[3 * r]) * exp((double)scale[3 * r + 1]) * exp((double)scale[3 * r + 2]);
+    const double op = 1.0 / (1.0 + exp(-(double)opacity[r]));
+    const float imp = (float)(size * op);  // Float32Array store
+    key[r] = ~__float_as_uint(imp);
+    idx[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(kRB) void iota_kernel(uint32_t* __restrict__ idx, long long n) {
+    const long long r = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (r < n) idx[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(kRB) void splat_pack_kernel(const uint32_t* __restrict__ order, long long n,
+                                                          const float* __restrict__ xyz, const float* __restrict__ scale,
+                                                          const float* __restrict__ rot, const float* __restrict__ opacity,
+                                                          const float* __restrict__ f_dc, const int* __restrict__ labels,
+                                                          uint4* __restrict__ buffer /*2 per splat*/,
+                                                          uint4* __restrict__ tex /*2 per splat*/) {
+    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (j >= n) return;
+    const long long r = order[j];
+    const float px = xyz[3 * r], py = xyz[3 * r + 1], pz = xyz[3 * r + 2];
+    float sc[3];
+    unsigned q[4];
+    if (scale) {
+        const double r0 = rot[4 * r], r1 = rot[4 * r + 1], r2 = rot[4 * r + 2], r3 = rot[4 * r + 3];
+        const double qlen = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);  // gs.js:549
+        q[0] = js_u8clamp((r0 / qlen) * 128.0 + 128.0);
+        q[1] = js_u8clamp((r1 / qlen) * 128.0 + 128.0);
+        q[2] = js_u8clamp((r2 / qlen) * 128.0 + 128.0);
+        q[3] = js_u8clamp((r3 / qlen) * 128.0 + 128.0);
+        sc[0] = (float)exp((double)scale[3 * r]);
+        sc[1] = (float)exp((double)scale[3 * r + 1]);
+        sc[2] = (float)exp((double)scale[3 * r + 2]);
+    } else {  // gs.js:559-563
+        sc[0] = sc[1] = sc[2] = (float)0.01;
+        q[0] = 255u;
+        q[1] = q[2] = q[3] = 0u;
+    }
+    const double SH_C0 = 0.28209479177387814;
+    unsigned c[4];
+    for (int k = 0; k < 3; ++k) c[k] = js_u8clamp((0.5 + SH_C0 * (double)f_dc[3 * r + k]) * 255.0);  // gs.js:567-569
+    c[3] = opacity ? js_u8clamp((1.0 / (1.0 + exp(-(double)opacity[r]))) * 255.0) : 255u;           // gs.js:576
+    const unsigned rgba = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
+    const unsigned quat = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    buffer[2 * j] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(sc[0]));
+    buffer[2 * j + 1] = make_uint4(__float_as_uint(sc[1]), __float_as_uint(sc[2]), rgba, quat);
+
+    // generateTexture, gs.js:322-353: covariance from the QUANTISED quaternion and the f32 scales, in fp64
+    double rt[4];
+    for (int k = 0; k < 4; ++k) rt[k] = ((double)q[k] - 128.0) / 128.0;
+    double M[9] = {
+        1.0 - 2.0 * (rt[2] * rt[2] + rt[3] * rt[3]), 2.0 * (rt[1] * rt[2] + rt[0] * rt[3]), 2.0 * (rt[1] * rt[3] - rt[0] * rt[2]),
+        2.0 * (rt[1] * rt[2] - rt[0] * rt[3]), 1.0 - 2.0 * (rt[1] * rt[1] + rt[3] * rt[3]), 2.0 * (rt[2] * rt[3] + rt[0] * rt[1]),
+        2.0 * (rt[1] * rt[3] + rt[0] * rt[2]), 2.0 * (rt[2] * rt[3] - rt[0] * rt[1]), 1.0 - 2.0 * (rt[1] * rt[1] + rt[2] * rt[2]),
+    };
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = M[k] * (double)sc[k / 3];
+    const double s0 = M[0] * M[0] + M[3] * M[3] + M[6] * M[6];
+    const double s1 = M[0] * M[1] + M[3] * M[4] + M[6] * M[7];
+    const double s2 = M[0] * M[2] + M[3] * M[5] + M[6] * M[8];
+    const double s3 = M[1] * M[1] + M[4] * M[4] + M[7] * M[7];
+    const double s4 = M[1] * M[2] + M[4] * M[5] + M[7] * M[8];
+    const double s5 = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
+    const unsigned h01 = js_float_to_half(4 * s0) | (js_float_to_half(4 * s1) << 16);
+    const unsigned h23 = js_float_to_half(4 * s2) | (js_float_to_half(4 * s3) << 16);
+    const unsigned h45 = js_float_to_half(4 * s4) | (js_float_to_half(4 * s5) << 16);
+    const float lab = (float)(labels ? labels[r] : -999999);  // NO_SELECTION, gs.js:6,579; texdata_f[..+3] = label
+    tex[2 * j] = make_uint4(__float_as_uint(px), __float_as_uint(py), __float_as_uint(pz), __float_as_uint(lab));
+    tex[2 * j + 1] = make_uint4(h01, h23, h45, rgba);
+}
+
+// ---- per view ------------------------------------------------------------------------------------------
+struct ViewUniforms {
+    double vp2, vp6, vp10;  // row 2 of proj*view (gs.js:437)
+    float view[16];         // uniforms as the GPU sees them: f32
+    float proj[16];
+    float fx, fy, W, H;
+    int tiles_x, tiles_y;
+};
+
+// depth = ((vp[2]*x + vp[6]*y + vp[10]*z) * 4096) | 0 and its min / max  (gs.js:436-441)
+__global__ __launch_bounds__(kRB) void depth_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
+                                                     int* __restrict__ depth, int* __restrict__ minmax) {
+    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
+    int d = 0, lo = 2147483647, hi = -2147483647 - 1;
+    if (i < n) {
+        const uint4 t = tex[2 * i];
+        const double x = (double)__uint_as_float(t.x), y = (double)__uint_as_float(t.y), z = (double)__uint_as_float(t.z);
+        d = js_toint32((u.vp2 * x + u.vp6 * y + u.vp10 * z) * 4096.0);
+        depth[i] = d;
+        lo = hi = d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+
+// bucket (gs.js:443-447) + vertex shader (gs.js:696-750) + tile rectangle
+__global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
+                                                          const int* __restrict__ depth, const int* __restrict__ minmax,
+                                                          const float* __restrict__ sh_rgb /* n x 3 or null */,
+                                                          float4* __restrict__ rec0, float4* __restrict__ rec1,
+                                                          float2* __restrict__ rec2, uint32_t* __restrict__ bucket,
+                                                          uint32_t* __restrict__ tile_rect, uint32_t* __restrict__ tile_count,
+                                                          int* __restrict__ dropped) {
+    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (i >= n) return;
+    const double minDepth = (double)minmax[0], maxDepth = (double)minmax[1];
+    const double depthInv = (256.0 * 256.0) / (maxDepth - minDepth);
+    const int b = js_toint32(((double)depth[i] - minDepth) * depthInv);
+    uint32_t count = 0, rect = 0;
+    const bool in_range = b >= 0 && b < 65536;  // the JS's typed arrays silently drop anything else
+    bucket[i] = in_range ? (uint32_t)b : 65536u;
+    if (!in_range) atomicAdd(dropped, 1);
+
+    // ---- vertex shader, fp32 ----
+    const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
+    const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
+    float cam[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cam[k] = u.view[k] * cx_ + u.view[4 + k] * cy_ + u.view[8 + k] * cz_ + u.view[12 + k] * 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p2[k] = u.proj[k] * cam[0] + u.proj[4 + k] * cam[1] + u.proj[8 + k] * cam[2] + u.proj[12 + k] * cam[3];
+    const float clip = 1.2f * p2[3];
+    bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    float2 r2 = make_float2(0.f, 0.f);
+    if (drawn) {
+        const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
+        const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
+        const float u3x = half_to_float(t1.z & 0xffffu), u3y = half_to_float(t1.z >> 16);
+        const float V[3][3] = {{u1x, u1y, u2x}, {u1y, u2y, u3x}, {u2x, u3x, u3y}};
+        const float ja = u.fx / cam[2], jb = -(u.fx * cam[0]) / (cam[2] * cam[2]);
+        const float jc = -u.fy / cam[2], jd = (u.fy * cam[1]) / (cam[2] * cam[2]);
+        float ta[3], tb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ta[k] = u.view[4 * k + 0] * ja + u.view[4 * k + 1] * 0.0f + u.view[4 * k + 2] * jb;
+            tb[k] = u.view[4 * k + 0] * 0.0f + u.view[4 * k + 1] * jc + u.view[4 * k + 2] * jd;
+        }
+        float a0[3], a1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a0[k] = ta[0] * V[k][0] + ta[1] * V[k][1] + ta[2] * V[k][2];
+            a1[k] = tb[0] * V[k][0] + tb[1] * V[k][1] + tb[2] * V[k][2];
+        }
+        const float c00 = a0[0] * ta[0] + a0[1] * ta[1] + a0[2] * ta[2];
+        const float c01 = a1[0] * ta[0] + a1[1] * ta[1] + a1[2] * ta[2];
+        const float c11 = a1[0] * tb[0] + a1[1] * tb[1] + a1[2] * tb[2];
+        const float mid = (c00 + c11) / 2.0f;
+        const float hx = (c00 - c11) / 2.0f;
+        const float radius = sqrtf(hx * hx + c01 * c01);
+        const float l1 = mid + radius, l2 = mid - radius;
+        if (l2 < 0.0f) drawn = false;  // gs.js:736
+        const float dx = c01, dy = l1 - c00;
+        const float dl = sqrtf(dx * dx + dy * dy);
+        const float ux = dx / dl, uy = dy / dl;
+        const float s1 = fminf(sqrtf(2.0f * l1), 1024.0f), s2 = fminf(sqrtf(2.0f * l2), 1024.0f);
+        const float mx = s1 * ux, my = s1 * uy;    // majorAxis
+        const float nx = s2 * uy, ny = s2 * -ux;   // minorAxis
+        float fade = p2[2] / p2[3] + 1.0f;
+        fade = fade < 0.0f ? 0.0f : (fade > 1.0f ? 1.0f : fade);
+        float col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
+        if (sh_rgb) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) col[k] = fade * sh_rgb[3 * i + k];
+        }
+        const float ndcx = p2[0] / p2[3], ndcy = p2[1] / p2[3];
+        const float wcx = (ndcx + 1.0f) * 0.5f * u.W;  // GL window coordinates, y up
+        const float wcy = (ndcy + 1.0f) * 0.5f * u.H;
+        const float m2 = mx * mx + my * my, n2 = nx * nx + ny * ny;
+        const float big = 3.0e38f;
+        if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
+        if (drawn) {
+            r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
+            r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
+            r2 = make_float2(col[2], col[3]);
+            // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
+            const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
+            const float top = u.H - wcy;  // image row coordinate of the centre
+            int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
+            int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
+            x0 = max(x0, 0);
+            y0 = max(y0, 0);
+            x1 = min(x1, (int)u.W - 1);
+            y1 = min(y1, (int)u.H - 1);
+            if (x1 >= x0 && y1 >= y0 && in_range) {
+                const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
+                rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
+                count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            }
+        }
+    }
+    rec0[i] = r0;
+    rec1[i] = r1;
+    rec2[i] = r2;
+    tile_rect[i] = rect;
+    tile_count[i] = count;
+}
+
+// ---- exclusive scan of u32 (3 launches: tile sums, scan of sums, downsweep) ---------------------------------
+static constexpr int kScanItems = 16;
+static constexpr int kScanTile = kRB * kScanItems;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wsum /*[4]*/, uint32_t& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    return off + inc - v;
+}
+
+__global__ __launch_bounds__(kRB) void scan_sums_kernel(const uint32_t* __restrict__ in, long long n,
+                                                         uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wsum[4];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t total;
+    (void)block_exclusive_scan(s, wsum, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kRB) void scan_top_kernel(uint32_t* __restrict__ sums, int m, uint32_t* __restrict__ grand) {
+    __shared__ uint32_t wsum[4];
+    uint32_t carry = 0;
+    for (int t0 = 0; t0 < m; t0 += kRB) {
+        const int t = t0 + threadIdx.x;
+        const uint32_t v = t < m ? sums[t] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, wsum, total);
+        if (t < m) sums[t] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *grand = carry;
+}
+
+__global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restrict__ in, long long n,
+                                                         const uint32_t* __restrict__ sums, uint32_t* __restrict__ out) {
+    __shared__ uint32_t wsum[4];
+    const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = base + k < n ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = sums[blockIdx.x] + block_exclusive_scan(s, wsum, total);
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---- emit (tile << 17 | bucket, splat) pairs, in splat order (stability of the later sort) --------------------
+__global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* __restrict__ tile_rect,
+                                                    const uint32_t* __restrict__ tile_count,
+                                                    const uint32_t* __restrict__ offset, const uint32_t* __restrict__ bucket,
+                                                    int tiles_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (i >= n || tile_count[i] == 0) return;
+    const uint32_t rect = tile_rect[i];
+    const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
+    uint32_t o = offset[i];
+    const uint32_t b = bucket[i];
+    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+            keys[o] = ((ty * (uint32_t)tiles_x + tx) << 17) | b;
+            vals[o] = (uint32_t)i;
+            ++o;
+        }
+}
+
+__global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, long long P,
+                                                      int2* __restrict__ ranges) {
+    const long long p = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (p >= P) return;
+    const uint32_t t = keys[p] >> 17;
+    if (p == 0 || (keys[p - 1] >> 17) != t) ranges[t].x = (int)p;
+    if (p == P - 1 || (keys[p + 1] >> 17) != t) ranges[t].y = (int)(p + 1);
+}
+
+// ---- host drivers -----------------------------------------------------------------------------------------
+static inline unsigned grid_for(long long n) { return (unsigned)((n + kRB - 1) / kRB); }
+
+static int exclusive_scan_u32(Ctx* c, const uint32_t* in, uint32_t* out, long long n, uint32_t* grand_dev) {
+    const int m = (int)((n + kScanTile - 1) / kScanTile);
+    GSX_HIP(c, c->r_scan.ensure(sizeof(uint32_t) * (size_t)(m + 1)));
+    uint32_t* sums = c->r_scan.as<uint32_t>();
+    {
+        ProfScope ps(c, "scan");
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(m), dim3(kRB), 0, c->stream, in, n, sums);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kRB), 0, c->stream, sums, m, grand_dev);
+        hipLaunchKernelGGL(scan_down_kernel, dim3(m), dim3(kRB), 0, c->stream, in, n, sums, out);
+    }
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const float* rot, const float* opacity,
+                  const float* f_dc, const int32_t* labels) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    c->rn = 0;
+    if (n < 0 || (n > 0 && (!xyz || !f_dc || (scale && (!rot || !opacity)))))
+        return fail(c, GSX_E_INVALID, "upload_splats: xyz and f_dc are required; scale needs rot and opacity");
+    if (n > ((int64_t)1 << 30)) return fail(c, GSX_E_UNSUPPORTED, "upload_splats: n > 2^30");
+    if (n == 0) return GSX_OK;
+    DevBuf dxyz, dscale, drot, dop, ddc, dlab, key0, key1, idx0, idx1;
+    auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
+        hipError_t e = b.ensure(bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream);
+    };
+    GSX_HIP(c, up(dxyz, xyz, sizeof(float) * 3 * n));
+    GSX_HIP(c, up(ddc, f_dc, sizeof(float) * 3 * n));
+    if (scale) {
+        GSX_HIP(c, up(dscale, scale, sizeof(float) * 3 * n));
+        GSX_HIP(c, up(drot, rot, sizeof(float) * 4 * n));
+    }
+    if (opacity) GSX_HIP(c, up(dop, opacity, sizeof(float) * n));
+    if (labels) GSX_HIP(c, up(dlab, labels, sizeof(int32_t) * n));
+    GSX_HIP(c, key0.ensure(4 * n));
+    GSX_HIP(c, key1.ensure(4 * n));
+    GSX_HIP(c, idx0.ensure(4 * n));
+    GSX_HIP(c, idx1.ensure(4 * n));
+    GSX_HIP(c, c->r_order.ensure(4 * n));
+    GSX_HIP(c, c->r_buffer.ensure(32 * n));
+    GSX_HIP(c, c->r_tex.ensure(32 * n));
+    int where = 0;
+    if (scale) {
+        hipLaunchKernelGGL(splat_importance_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, dscale.as<float>(),
+                           dop.as<float>(), (long long)n, key0.as<uint32_t>(), idx0.as<uint32_t>());
+        GSX_HIP(c, hipGetLastError());
+        int rc = radix_sort_pairs(c, key0.as<uint32_t>(), idx0.as<uint32_t>(), key1.as<uint32_t>(), idx1.as<uint32_t>(), n, 32,
+                                  &where);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, idx0.as<uint32_t>(), (long long)n);
+    }
+    GSX_HIP(c, hipMemcpyAsync(c->r_order.p, where ? idx1.p : idx0.p, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+    {
+        ProfScope ps(c, "splat_pack");
+        hipLaunchKernelGGL(splat_pack_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_order.as<uint32_t>(),
+                           (long long)n, dxyz.as<float>(), scale ? dscale.as<float>() : nullptr,
+                           scale ? drot.as<float>() : nullptr, opacity ? dop.as<float>() : nullptr, ddc.as<float>(),
+                           labels ? dlab.as<int>() : nullptr, c->r_buffer.as<uint4>(), c->r_tex.as<uint4>());
+    }
+    GSX_HIP(c, hipGetLastError());
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    c->rn = n;
+    c->r_sh_valid = false;
+    return GSX_OK;
+}
+
+// gs.js:81-107 and 66-79, fp64 exactly as the JavaScript evaluates them
+void js_view_matrix(const gsx_camera* cam, double out[16]) {
+    const double* R = cam->R;
+    const double* p = cam->p;
+    for (int i = 0; i < 3; ++i) {
+        out[4 * i + 0] = R[3 * i + 0];
+        out[4 * i + 1] = R[3 * i + 1];
+        out[4 * i + 2] = R[3 * i + 2];
+        out[4 * i + 3] = 0.0;
+    }
+    for (int i = 0; i < 3; ++i) out[12 + i] = -p[0] * R[i] - p[1] * R[i + 3] - p[2] * R[i + 6];
+    out[15] = 1.0;
+}
+
+void js_proj_matrix(double fx, double fy, double width, double height, double out[16]) {
+    const double Z_FAR = 200.0, Z_NEAR = 0.2;
+    const double zRange = Z_FAR - Z_NEAR;
+    for (int k = 0; k < 16; ++k) out[k] = 0.0;
+    out[0] = (2 * fx) / width;
+    out[5] = -(2 * fy) / height;
+    out[10] = Z_FAR / zRange;
+    out[11] = 1.0;
+    out[14] = -(Z_FAR * Z_NEAR) / zRange;
+}
+
+void js_multiply4(const double A[16], const double B[16], double out[16]) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            out[4 * i + j] = B[4 * i] * A[j] + B[4 * i + 1] * A[j + 4] + B[4 * i + 2] * A[j + 8] + B[4 * i + 3] * A[j + 12];
+}
+
+int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev);  // blend.hip
+
+int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    if (!cam || W < 1 || H < 1) return fail(c, GSX_E_INVALID, "render_view: bad arguments");
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
+    if (tiles_x > 256 || tiles_y > 256 || (long long)tiles_x * tiles_y > 32767)
+        return fail(c, GSX_E_UNSUPPORTED, "render_view: %dx%d needs more than 32767 16x16 tiles", W, H);
+    const long long n = c->rn;
+    const size_t img_bytes = sizeof(float) * 4 * (size_t)W * H;
+    GSX_HIP(c, c->r_image.ensure(img_bytes));
+    c->r_W = W;
+    c->r_H = H;
+    const int ntiles = tiles_x * tiles_y;
+    GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)ntiles));
+    GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)ntiles, c->stream));
+    GSX_HIP(c, c->r_small.ensure(64));
+    int* minmax = c->r_small.as<int>();        // [0]=min [1]=max [2]=dropped [3]=P
+    const int init[4] = {2147483647, -2147483647 - 1, 0, 0};
+    GSX_HIP(c, hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    c->r_P = 0;
+    if (n > 0) {
+        ViewUniforms u{};
+        double view[16], proj[16], vp[16];
+        js_view_matrix(cam, view);
+        js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
+        js_multiply4(proj, view, vp);
+        u.vp2 = vp[2];
+        u.vp6 = vp[6];
+        u.vp10 = vp[10];
+        for (int k = 0; k < 16; ++k) {  // gl.uniformMatrix4fv: JS numbers -> f32
+            u.view[k] = (float)view[k];
+            u.proj[k] = (float)proj[k];
+        }
+        u.fx = (float)cam->fx;
+        u.fy = (float)cam->fy;
+        u.W = (float)W;
+        u.H = (float)H;
+        u.tiles_x = tiles_x;
+        u.tiles_y = tiles_y;
+        const size_t n4 = 4 * (size_t)n;
+        GSX_HIP(c, c->r_depth.ensure(n4));
+        GSX_HIP(c, c->r_bucket.ensure(n4));
+        GSX_HIP(c, c->r_rect.ensure(n4));
+        GSX_HIP(c, c->r_count.ensure(n4));
+        GSX_HIP(c, c->r_offset.ensure(n4));
+        GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
+        GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
+        GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
+        {
+            ProfScope ps(c, "render_depth");
+            hipLaunchKernelGGL(depth_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
+                               c->r_depth.as<int>(), minmax);
+        }
+        {
+            ProfScope ps(c, "render_preprocess");
+            hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
+                               c->r_depth.as<int>(), minmax, c->r_sh_valid ? c->r_sh.as<float>() : nullptr,
+                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), c->r_bucket.as<uint32_t>(),
+                               c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2);
+        }
+        GSX_HIP(c, hipGetLastError());
+        int rc = exclusive_scan_u32(c, c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), n, (uint32_t*)(minmax + 3));
+        if (rc) return rc;
+        uint32_t P = 0;
+        GSX_HIP(c, hipMemcpyAsync(&P, minmax + 3, 4, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        c->r_P = P;
+        if (P > 0) {
+            GSX_HIP(c, c->r_keys0.ensure(4 * (size_t)P));
+            GSX_HIP(c, c->r_keys1.ensure(4 * (size_t)P));
+            GSX_HIP(c, c->r_vals0.ensure(4 * (size_t)P));
+            GSX_HIP(c, c->r_vals1.ensure(4 * (size_t)P));
+            {
+                ProfScope ps(c, "render_emit");
+                hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, n, c->r_rect.as<uint32_t>(),
+                                   c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), c->r_bucket.as<uint32_t>(), tiles_x,
+                                   c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>());
+            }
+            GSX_HIP(c, hipGetLastError());
+            int tile_bits = 1;
+            while ((1 << tile_bits) < ntiles) ++tile_bits;
+            int where = 0;
+            rc = radix_sort_pairs(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
+                                  c->r_vals1.as<uint32_t>(), P, 17 + tile_bits, &where);
+            if (rc) return rc;
+            c->r_sorted_in = where;
+            {
+                ProfScope ps(c, "render_ranges");
+                hipLaunchKernelGGL(ranges_kernel, dim3(grid_for(P)), dim3(kRB), 0, c->stream,
+                                   where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), (long long)P,
+                                   c->r_ranges.as<int2>());
+            }
+            GSX_HIP(c, hipGetLastError());
+        }
+    }
+    int rc = launch_blend(c, W, H, tiles_x, tiles_y, minmax + 2);
+    if (rc) return rc;
+    if (rgba_out) GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int render_debug(Ctx* c, uint8_t* buffer_out, uint32_t* order_out, uint32_t* tex_out, uint32_t* bucket_out) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    const size_t n = (size_t)c->rn;
+    if (n == 0) return GSX_OK;
+    if (buffer_out) GSX_HIP(c, hipMemcpyAsync(buffer_out, c->r_buffer.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    if (order_out) GSX_HIP(c, hipMemcpyAsync(order_out, c->r_order.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    if (tex_out) GSX_HIP(c, hipMemcpyAsync(tex_out, c->r_tex.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    if (bucket_out) {
+        if (c->r_bucket.cap < 4 * n) return fail(c, GSX_E_STATE, "render_debug: no view has been rendered yet");
+        GSX_HIP(c, hipMemcpyAsync(bucket_out, c->r_bucket.p, 4 * n, hipMemcpyDeviceToHost, c->stream));
+    }
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+}  // namespace gsx

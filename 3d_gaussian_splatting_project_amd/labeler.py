@@ -158,6 +158,44 @@ class Context:
         check(self._lib.gsx_vote_debug_planes(self.h, cnt.ctypes.data, fv.ctypes.data), self.h)
         return cnt, fv
 
+    # -- rasterizer ---------------------------------------------------------------------------------
+    def upload_splats(self, xyz, scale, rot, opacity, f_dc, labels=None):
+        """3DGS PLY attributes as float arrays (see include/gsx.h).  scale/opacity may be None."""
+        f32 = lambda a, w: None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1, w))
+        xyz, scale, rot, f_dc = f32(xyz, 3), f32(scale, 3), f32(rot, 4), f32(f_dc, 3)
+        opacity = None if opacity is None else np.ascontiguousarray(np.asarray(opacity, dtype=np.float32).reshape(-1))
+        lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+        n = len(xyz)
+        for a in (scale, rot, opacity, f_dc, lab):
+            if a is not None and len(a) != n:
+                raise ValueError("all splat attribute arrays must have the same number of rows")
+        ptr = lambda a: None if a is None else a.ctypes.data
+        check(self._lib.gsx_upload_splats(self.h, n, ptr(xyz), ptr(scale), ptr(rot), ptr(opacity), ptr(f_dc), ptr(lab)),
+              self.h)
+        self.n_splats = n
+
+    def render_view(self, camera, width, height, to_host=True):
+        """One frame of the viewer's pipeline -> (height, width, 4) float32 premultiplied RGBA."""
+        cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
+        out = np.empty((height, width, 4), np.float32) if to_host else None
+        check(self._lib.gsx_render_view(self.h, C.byref(cam), int(width), int(height), out.ctypes.data if to_host else None),
+              self.h)
+        return out
+
+    def render_num_pairs(self):
+        return self._lib.gsx_render_num_pairs(self.h)
+
+    def render_debug(self, buckets=False):
+        """(buffer (n,32) u8, order (n,) u32, texdata (8n,) u32[, buckets (n,) u32]) — test hooks."""
+        n = self.n_splats
+        buf = np.empty((n, 32), np.uint8)
+        order = np.empty(n, np.uint32)
+        tex = np.empty(8 * n, np.uint32)
+        bk = np.empty(n, np.uint32) if buckets else None
+        check(self._lib.gsx_render_debug(self.h, buf.ctypes.data, order.ctypes.data, tex.ctypes.data,
+                                         bk.ctypes.data if buckets else None), self.h)
+        return (buf, order, tex, bk) if buckets else (buf, order, tex)
+
     def sort_pairs(self, keys, values, bits=32):
         """Stable GPU radix sort by key bits [0, bits) (test hook, gsx_debug_sort_pairs)."""
         k = np.ascontiguousarray(keys, dtype=np.uint32).copy()

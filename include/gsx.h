@@ -142,6 +142,34 @@ int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out);
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out);
 
 /* ---------------------------------------------------------------------------------------------
+ * rasterizer — the viewer's GPU/worker path (gs.js) as tile-based HIP kernels
+ *
+ *   gsx_upload_splats    processPlyBuffer gs.js:464-585 (importance order, u8 quantisation, 32-byte
+ *                        .splat rows) + generateTexture gs.js:286-357 (4*Sigma as truncated fp16)
+ *   gsx_render_view      getViewMatrix/calculateProjectionMatrix gs.js:66-107, runSort gs.js:417-462
+ *                        (front-to-back 16-bit depth buckets, stable), vertex shader gs.js:696-750,
+ *                        fragment shader + blend gs.js:782-799, 1033-1038
+ * Inputs are the 3DGS PLY attributes as float arrays (AoS per attribute, row i = vertex i):
+ *   xyz n x 3, scale n x 3 (log), rot n x 4 (w first), opacity n (logit), f_dc n x 3, labels n (or NULL).
+ *   scale == NULL selects the viewer's fallback (scale 0.01, identity rotation, gs.js:559-563);
+ *   opacity == NULL -> alpha 255 (gs.js:576).
+ * rgba_out: height x width x 4 floats, row 0 = top row, premultiplied colour exactly as the fragment
+ * shader emits it (float, not the canvas's 8-bit quantisation); NULL leaves the image on the device.
+ * ------------------------------------------------------------------------------------------- */
+int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* scale, const float* rot,
+                      const float* opacity, const float* f_dc, const int32_t* labels);
+int64_t gsx_num_splats(const gsx_ctx* ctx);
+int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out);
+void* gsx_render_image_device(gsx_ctx* ctx);
+/* number of (tile, splat) pairs the last gsx_render_view sorted and blended */
+int64_t gsx_render_num_pairs(const gsx_ctx* ctx);
+/* test hooks (any pointer may be NULL): the packed .splat rows (n x 32 bytes) and importance
+ * permutation (gs.js:527), the texture words (n x 8 u32, gs.js:311-353) and the last view's 16-bit
+ * depth buckets (65536 = dropped by the JS counting sort, gs.js:443-457) */
+int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uint32_t* texdata_out,
+                     uint32_t* bucket_out);
+
+/* ---------------------------------------------------------------------------------------------
  * test hook: the library's stable LSD radix sort of (u32 key, u32 value) pairs by key bits
  * [0, bits) — the primitive behind the Morton ordering and the rasterizer's (tile | depth16) order,
  * which restates the stable counting sort of gs.js:443-457.  Host arrays, sorted in place.

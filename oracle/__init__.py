@@ -157,7 +157,8 @@ class NumpyVoteShard:
 # ---- viewer path (oracle/render_oracle.c) ---------------------------------------------------------
 class VertexOut(C.Structure):
     _fields_ = [("drawn", C.c_int32), ("cx", C.c_float), ("cy", C.c_float), ("major", C.c_float * 2),
-                ("minor", C.c_float * 2), ("color", C.c_float * 4), ("fade", C.c_float)]
+                ("minor", C.c_float * 2), ("color", C.c_float * 4), ("fade", C.c_float),
+                ("g0", C.c_float * 2), ("g1", C.c_float * 2)]
 
 
 def _f32(a):

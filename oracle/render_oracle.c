@@ -269,6 +269,8 @@ typedef struct {
     float minor[2];    /* gs.js:739 */
     float color[4];    /* vColor, gs.js:741-742 */
     float fade;        /* clamp(z/w + 1, 0, 1), the factor inside vColor */
+    float g0[2];       /* 2*major/|major|^2 : vPosition.x = dot(d, g0) for a window offset d from the centre */
+    float g1[2];       /* 2*minor/|minor|^2 : vPosition.y = dot(d, g1) */
 } gsxo_vertex_out;
 
 static float half_to_float(uint32_t h) {
@@ -337,6 +339,13 @@ void gsxo_vertex(const uint32_t* texel8, const float view[16], const float proj[
     const float n2 = o->minor[0] * o->minor[0] + o->minor[1] * o->minor[1];
     /* a quad with a zero or non-finite axis has no area / no valid position: nothing is rasterised */
     if (!(m2 > 0.0f) || !(n2 > 0.0f) || !isfinite(m2) || !isfinite(n2) || !isfinite(o->cx) || !isfinite(o->cy)) return;
+    /* The rasteriser interpolates `position` (corners +-2) linearly over the quad whose window-space
+     * half-diagonals are major and minor (orthogonal): a pixel at offset d from the centre gets
+     * vPosition = (2 d.major/|major|^2, 2 d.minor/|minor|^2). */
+    o->g0[0] = 2.0f * o->major[0] / m2;
+    o->g0[1] = 2.0f * o->major[1] / m2;
+    o->g1[0] = 2.0f * o->minor[0] / n2;
+    o->g1[1] = 2.0f * o->minor[1] / n2;
     o->drawn = 1;
 }
 
@@ -364,8 +373,6 @@ void gsxo_render_view(int64_t n, const uint32_t* texdata, const uint32_t* depth_
         if (!v.drawn) continue;
         if (override_color) /* SH colour path: the depth fade multiplies whatever rgb the splat has */
             for (int q = 0; q < 3; ++q) v.color[q] = v.fade * override_color[4 * (size_t)i + q];
-        const float m2 = v.major[0] * v.major[0] + v.major[1] * v.major[1];
-        const float n2 = v.minor[0] * v.minor[0] + v.minor[1] * v.minor[1];
         const float ex = sqrtf(v.major[0] * v.major[0] + v.minor[0] * v.minor[0]) + 1.0f;
         const float ey = sqrtf(v.major[1] * v.major[1] + v.minor[1] * v.minor[1]) + 1.0f;
         /* window y is up; image row r has its centre at yw = H - (r + 0.5) */
@@ -379,8 +386,8 @@ void gsxo_render_view(int64_t n, const uint32_t* texdata, const uint32_t* depth_
             const float dy = ((float)H - ((float)r + 0.5f)) - v.cy;
             for (int x = x0; x <= x1; ++x) {
                 const float dx = ((float)x + 0.5f) - v.cx;
-                const float vx = 2.0f * (dx * v.major[0] + dy * v.major[1]) / m2; /* interpolated vPosition */
-                const float vy = 2.0f * (dx * v.minor[0] + dy * v.minor[1]) / n2;
+                const float vx = dx * v.g0[0] + dy * v.g0[1]; /* interpolated vPosition */
+                const float vy = dx * v.g1[0] + dy * v.g1[1];
                 const float A = -(vx * vx + vy * vy);
                 if (A < -4.0f) continue; /* discard, gs.js:784 */
                 const float B = expf(A) * v.color[3];
