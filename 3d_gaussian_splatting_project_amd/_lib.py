@@ -71,11 +71,22 @@ _SIGS = {
     "gsx_vote_labels_from_keys": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_upload_splats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6),
+    "gsx_upload_sh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gsx_num_splats": (C.c_int64, [C.c_void_p]),
     "gsx_render_view": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_void_p]),
     "gsx_render_image_device": (C.c_void_p, [C.c_void_p]),
     "gsx_render_num_pairs": (C.c_int64, [C.c_void_p]),
     "gsx_render_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
+    "gsx_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "gsx_ply_close": (None, [C.c_void_p]),
+    "gsx_ply_num_vertices": (C.c_int64, [C.c_void_p]),
+    "gsx_ply_num_properties": (C.c_int32, [C.c_void_p]),
+    "gsx_ply_property": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "gsx_ply_row_stride": (C.c_int64, [C.c_void_p]),
+    "gsx_ply_rows": (C.c_void_p, [C.c_void_p]),
+    "gsx_ply_read_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "gsx_ply_set_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
+    "gsx_ply_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsx_profile_reset": (C.c_int, [C.c_void_p]),

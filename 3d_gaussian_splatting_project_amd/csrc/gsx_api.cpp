@@ -119,7 +119,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
-                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_image,
+                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1})
         b->release();
@@ -299,6 +299,10 @@ int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* sc
                       const float* opacity, const float* f_dc, const int32_t* labels) {
     CTX_OR_FAIL(ctx);
     return gsx::upload_splats(c, n, xyz, scale, rot, opacity, f_dc, labels);
+}
+int gsx_upload_sh(gsx_ctx* ctx, const float* f_rest, int32_t sh_degree) {
+    CTX_OR_FAIL(ctx);
+    return gsx::upload_sh(c, f_rest, sh_degree);
 }
 int64_t gsx_num_splats(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);

@@ -123,7 +123,9 @@ struct Ctx {
     int64_t rn = 0;                      // splats uploaded
     DevBuf r_order, r_buffer, r_tex;     // importance permutation, .splat rows, texel pairs
     DevBuf r_sh;                         // per-view SH colour (n x 3 f32)
-    bool r_sh_valid = false;
+    DevBuf r_fdc, r_shc;                 // f_dc (source order); SH coefficients coef[k][i][3] (importance order)
+    bool r_sh_valid = false, r_sh_on = false;
+    int r_sh_deg = 0;
     DevBuf r_image;                      // float4[H][W] of the last view
     int r_W = 0, r_H = 0;
     DevBuf r_ranges, r_small, r_scan;
@@ -168,6 +170,7 @@ int spatial_sort_positions(Ctx* c);
 // render.hip
 int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const float* rot, const float* opacity,
                   const float* f_dc, const int32_t* labels);
+int upload_sh(Ctx* c, const float* f_rest, int deg);
 int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out);
 int render_debug(Ctx* c, uint8_t* buffer_out, uint32_t* order_out, uint32_t* tex_out, uint32_t* bucket_out);
 void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);

@@ -162,6 +162,70 @@ __global__ __launch_bounds__(kRB) void splat_pack_kernel(const uint32_t* __restr
     tex[2 * j + 1] = make_uint4(h01, h23, h45, rgba);
 }
 
+// ---- spherical-harmonics colour (degrees 1..3; not in the reference, see oracle/render_oracle.c) ----------
+// coefficients re-laid at upload as coef[k][i][c] (k = 0 is f_dc), importance order: per view every
+// thread reads its K triples from K coalesced planes.
+__global__ __launch_bounds__(kRB) void sh_pack_kernel(const uint32_t* __restrict__ order, long long n,
+                                                       const float* __restrict__ f_dc, const float* __restrict__ f_rest,
+                                                       int K, float* __restrict__ coef) {
+    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (j >= n) return;
+    const long long r = order[j];
+    const int K1 = K - 1;
+    for (int c = 0; c < 3; ++c) {
+        coef[((size_t)0 * n + j) * 3 + c] = f_dc[3 * r + c];
+        for (int k = 1; k < K; ++k) coef[((size_t)k * n + j) * 3 + c] = f_rest[(size_t)r * 3 * K1 + (size_t)c * K1 + (k - 1)];
+    }
+}
+
+__global__ __launch_bounds__(kRB) void sh_color_kernel(const uint4* __restrict__ tex, long long n,
+                                                        const float* __restrict__ coef, int deg, float cpx, float cpy,
+                                                        float cpz, float* __restrict__ rgb) {
+    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (i >= n) return;
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const uint4 t = tex[2 * i];
+    const float dx = __uint_as_float(t.x) - cpx, dy = __uint_as_float(t.y) - cpy, dz = __uint_as_float(t.z) - cpz;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    float b[16];
+    b[0] = C0;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[1] = -C1 * y;
+    b[2] = C1 * z;
+    b[3] = -C1 * x;
+    b[4] = C2[0] * xy;
+    b[5] = C2[1] * yz;
+    b[6] = C2[2] * (2.0f * zz - xx - yy);
+    b[7] = C2[3] * xz;
+    b[8] = C2[4] * (xx - yy);
+    b[9] = C3[0] * y * (3.0f * xx - yy);
+    b[10] = C3[1] * xy * z;
+    b[11] = C3[2] * y * (4.0f * zz - xx - yy);
+    b[12] = C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+    b[13] = C3[4] * x * (4.0f * zz - xx - yy);
+    b[14] = C3[5] * z * (xx - yy);
+    b[15] = C3[6] * x * (xx - 3.0f * yy);
+    const int K = (deg + 1) * (deg + 1);
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if (k < K) {
+            const float* p = coef + ((size_t)k * n + i) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * p[c] : acc[c] + b[k] * p[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = acc[c] + 0.5f;
+        rgb[3 * i + c] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
 // ---- per view ------------------------------------------------------------------------------------------
 struct ViewUniforms {
     double vp2, vp6, vp10;  // row 2 of proj*view (gs.js:437)
@@ -420,7 +484,9 @@ int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const
         return fail(c, GSX_E_INVALID, "upload_splats: xyz and f_dc are required; scale needs rot and opacity");
     if (n > ((int64_t)1 << 30)) return fail(c, GSX_E_UNSUPPORTED, "upload_splats: n > 2^30");
     if (n == 0) return GSX_OK;
-    DevBuf dxyz, dscale, drot, dop, ddc, dlab, key0, key1, idx0, idx1;
+    DevBuf dxyz, dscale, drot, dop, dlab, key0, key1, idx0, idx1;
+    DevBuf& ddc = c->r_fdc;  // kept (source order): gsx_upload_sh re-lays it with f_rest
+    c->r_sh_deg = 0;
     auto up = [&](DevBuf& b, const void* src, size_t bytes) -> hipError_t {
         hipError_t e = b.ensure(bytes);
         if (e != hipSuccess) return e;
@@ -464,6 +530,7 @@ int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     c->rn = n;
     c->r_sh_valid = false;
+    c->r_sh_on = false;
     return GSX_OK;
 }
 
@@ -496,6 +563,29 @@ void js_multiply4(const double A[16], const double B[16], double out[16]) {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
             out[4 * i + j] = B[4 * i] * A[j] + B[4 * i + 1] * A[j + 4] + B[4 * i + 2] * A[j + 8] + B[4 * i + 3] * A[j + 12];
+}
+
+int upload_sh(Ctx* c, const float* f_rest, int deg) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    if (deg < 0 || deg > 3) return fail(c, GSX_E_INVALID, "upload_sh: degree %d outside [0,3]", deg);
+    if (c->rn == 0) return fail(c, GSX_E_STATE, "upload_sh before upload_splats");
+    if (deg > 0 && !f_rest) return fail(c, GSX_E_INVALID, "upload_sh: f_rest is NULL");
+    const long long n = c->rn;
+    const int K = (deg + 1) * (deg + 1);
+    DevBuf drest;
+    if (K > 1) {
+        GSX_HIP(c, drest.ensure(sizeof(float) * 3 * (size_t)(K - 1) * n));
+        GSX_HIP(c, hipMemcpyAsync(drest.p, f_rest, sizeof(float) * 3 * (size_t)(K - 1) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    GSX_HIP(c, c->r_shc.ensure(sizeof(float) * 3 * (size_t)K * n));
+    GSX_HIP(c, c->r_sh.ensure(sizeof(float) * 3 * (size_t)n));
+    hipLaunchKernelGGL(sh_pack_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_order.as<uint32_t>(), n,
+                       c->r_fdc.as<float>(), K > 1 ? drest.as<float>() : nullptr, K, c->r_shc.as<float>());
+    GSX_HIP(c, hipGetLastError());
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    c->r_sh_deg = deg;
+    c->r_sh_on = true;
+    return GSX_OK;
 }
 
 int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev);  // blend.hip
@@ -547,6 +637,14 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
         GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
         GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
+        c->r_sh_valid = false;
+        if (c->r_sh_on) {
+            ProfScope ps(c, "render_sh");
+            hipLaunchKernelGGL(sh_color_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n,
+                               c->r_shc.as<float>(), c->r_sh_deg, (float)cam->p[0], (float)cam->p[1], (float)cam->p[2],
+                               c->r_sh.as<float>());
+            c->r_sh_valid = true;
+        }
         {
             ProfScope ps(c, "render_depth");
             hipLaunchKernelGGL(depth_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,

@@ -174,6 +174,14 @@ class Context:
               self.h)
         self.n_splats = n
 
+    def upload_sh(self, f_rest, degree):
+        """Switch the colour path to float spherical harmonics of `degree` (see gsx_upload_sh)."""
+        k1 = (degree + 1) ** 2 - 1
+        fr = None
+        if k1:
+            fr = np.ascontiguousarray(np.asarray(f_rest, dtype=np.float32).reshape(self.n_splats, 3 * k1))
+        check(self._lib.gsx_upload_sh(self.h, None if fr is None else fr.ctypes.data, int(degree)), self.h)
+
     def render_view(self, camera, width, height, to_host=True):
         """One frame of the viewer's pipeline -> (height, width, 4) float32 premultiplied RGBA."""
         cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)

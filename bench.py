@@ -43,9 +43,49 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--order", default="input", choices=["input", "morton_host"],
                     help="experiment: pre-sort the Gaussians on the host before upload")
+    ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
+    ap.add_argument("--render-splats", type=int, default=3_000_000)
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     return ap.parse_args()
+
+
+def render_leg(pkg, ctx, args, W, H):
+    """Forward rasterizer on the same kind of scene (SH degree 3, viewer camera convention): views/s,
+    per-kernel HIP-event times and the blend kernel's algorithmic bytes / time."""
+    scene = pkg.scene
+    n = args.render_splats
+    seed = scene.BASE_SEED + 3
+    xyz = scene.make_positions(n, seed)
+    a = scene.make_splat_attributes(n, seed, sh_degree=3)
+    cams = scene.make_cameras(max(args.render_views, 8), W, H, convention="c2w")[:args.render_views]
+    ctx.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+    ctx.upload_sh(a["f_rest"], 3)
+    ctx.render_view(cams[0], W, H, to_host=False)          # warm-up
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    pairs = 0
+    for cam in cams:
+        ctx.render_view(cam, W, H, to_host=False)
+        pairs += ctx.render_num_pairs()
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    names = ["render_sh", "render_depth", "render_preprocess", "scan", "render_emit", "radix_hist", "radix_rowscan",
+             "radix_scatter", "render_ranges", "render_blend"]
+    k_ms = {k: round(ctx.profile_get(k)[1] / len(cams), 4) for k in names}
+    ctx.profile(False)
+    P = pairs / len(cams)
+    blend_ms = k_ms["render_blend"]
+    # blend: 4 B sorted index + 40 B record per (tile, splat) pair it consumes (upper bound: all pairs) + 16 B/pixel out
+    alg = P * 44.0 + W * H * 16.0
+    achieved = alg / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else None
+    return {"views": len(cams), "splats": n, "sh_degree": 3, "width": W, "height": H,
+            "views_per_s": round(len(cams) / dt, 2), "gaussian_views_per_s": round(n * len(cams) / dt, 1),
+            "tile_splat_pairs_per_view": int(P), "kernel_ms_per_view": k_ms,
+            "blend_roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
+                               "algorithmic_bytes": int(alg),
+                               "note": "blend is VALU/exp-bound at 16x16 tiles (SURVEY 7.6); see DESIGN.md"}}
 
 
 def main():
@@ -186,6 +226,11 @@ def main():
                "sample": f"first {m} Gaussians x {V} views @{W}x{H} (same scene), oracle/vote_oracle.c, OpenMP",
                "seconds": round(dt, 2), "labels_match_gpu": parity}
 
+    # ---- rasterizer leg (reported beside the headline metric, never part of `value`) ---------------------
+    render = None
+    if rank == 0 and world == 1 and args.render_views > 0:
+        render = render_leg(pkg, ctx, args, W, H)
+
     if rank == 0:
         out = {
             "metric": "Gaussian-views/sec labelled (3M Gaussians, 1080p views, majority vote)",
@@ -201,6 +246,7 @@ def main():
                        "setup_seconds": round(setup_s, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "render": render,
         }
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -158,6 +158,13 @@ int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_ou
  * ------------------------------------------------------------------------------------------- */
 int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* scale, const float* rot,
                       const float* opacity, const float* f_dc, const int32_t* labels);
+/* Optional view-dependent colour: spherical harmonics of degree 0..3 (standard 3DGS real-SH basis,
+ * dir = normalize(position - camera position), rgb = clamp(0.5 + SH, 0, 1) in float).  NOT part of the
+ * reference (gs.js:565-569 reads only f_dc and quantises it to 8 bits): once this is called the float
+ * SH colour replaces rgba8/255; geometry, alpha and depth fade stay the reference's.  f_rest: n x
+ * 3*((d+1)^2-1) floats in 3DGS PLY order (f_rest_[c*K1 + k-1]); NULL for degree 0.  Call after
+ * gsx_upload_splats; a new gsx_upload_splats switches it off again. */
+int gsx_upload_sh(gsx_ctx* ctx, const float* f_rest, int32_t sh_degree);
 int64_t gsx_num_splats(const gsx_ctx* ctx);
 int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out);
 void* gsx_render_image_device(gsx_ctx* ctx);
@@ -168,6 +175,35 @@ int64_t gsx_render_num_pairs(const gsx_ctx* ctx);
  * depth buckets (65536 = dropped by the JS counting sort, gs.js:443-457) */
 int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uint32_t* texdata_out,
                      uint32_t* bucket_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * PLY files — replaces the plyfile calls of the reference: PlyData.read (dls.py:29, ply_handler.py:
+ * 44-45) and PlyData([vertex], text=False).write (dls.py:331-332, ply_handler.py:35-37).
+ * Only the vertex element (scalar properties) is kept, as save_labeled_ply does.  ascii and
+ * binary_little_endian are read; rows are exposed in binary little-endian layout either way.
+ * These entry points need no GPU and no ctx (errors: gsx_last_error(NULL)).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct gsx_ply gsx_ply;
+typedef enum gsx_ply_type {
+    GSX_PLY_CHAR = 0, GSX_PLY_UCHAR = 1, GSX_PLY_SHORT = 2, GSX_PLY_USHORT = 3,
+    GSX_PLY_INT = 4, GSX_PLY_UINT = 5, GSX_PLY_FLOAT = 6, GSX_PLY_DOUBLE = 7
+} gsx_ply_type;
+int gsx_ply_open(const char* path, gsx_ply** out);
+void gsx_ply_close(gsx_ply* ply);
+int64_t gsx_ply_num_vertices(const gsx_ply* ply);
+int32_t gsx_ply_num_properties(const gsx_ply* ply);
+/* i-th vertex property: name (owned by ply), gsx_ply_type, byte offset inside a row */
+int gsx_ply_property(const gsx_ply* ply, int32_t i, const char** name, int32_t* type, int64_t* offset);
+int64_t gsx_ply_row_stride(const gsx_ply* ply);
+/* the vertex rows (num_vertices x row_stride bytes): a private copy-on-write mapping of the file or a
+ * parsed buffer; writable, never written back to the source file; feeds gsx_upload_positions_strided */
+void* gsx_ply_rows(gsx_ply* ply);
+/* one property as floats (any scalar type is converted) / overwrite one property from floats */
+int gsx_ply_read_f32(const gsx_ply* ply, const char* name, float* out);
+int gsx_ply_set_f32(gsx_ply* ply, const char* name, const float* in);
+/* writes every vertex property, plus a trailing `property int label` when labels != NULL
+ * (save_labeled_ply, dls.py:318-332).  text != 0 writes ascii (k_means.py:193). */
+int gsx_ply_write(const gsx_ply* ply, const char* path, const int32_t* labels, int32_t text);
 
 /* ---------------------------------------------------------------------------------------------
  * test hook: the library's stable LSD radix sort of (u32 key, u32 value) pairs by key bits

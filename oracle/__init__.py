@@ -277,3 +277,29 @@ def render_scene(xyz, scale, rot, opacity, f_dc, cam, W, H, labels=None):
     vp = multiply4(proj_matrix(cam["fx"], cam["fy"], W, H), view_matrix(cam))
     di, _ = depth_order(buf, vp)
     return render_view(tex, di, cam, W, H)
+
+
+def sh_colors(xyz, f_dc, f_rest, degree, campos):
+    """Per-splat view-dependent rgb (n,4; alpha slot 0) for render_view(override_color=...)."""
+    xyz, f_dc = _f32(xyz), _f32(f_dc)
+    n = len(xyz)
+    k1 = (degree + 1) ** 2 - 1
+    fr = _f32(f_rest) if k1 else np.zeros((n, 0), np.float32)
+    assert fr.shape == (n, 3 * k1)
+    cp = np.ascontiguousarray(campos, dtype=np.float64)
+    out = np.zeros((n, 4), np.float32)
+    f = lib().gsxo_sh_colors
+    f.restype = None
+    f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    f(n, xyz.ctypes.data, f_dc.ctypes.data, fr.ctypes.data if k1 else None, degree, cp.ctypes.data, out.ctypes.data)
+    return out
+
+
+def render_scene_sh(xyz, scale, rot, opacity, f_dc, f_rest, degree, cam, W, H):
+    """Viewer path with SH colour of the given degree (degree 0 still goes through the float colour path)."""
+    buf, order = pack_splats(xyz, scale, rot, opacity, f_dc)
+    tex = texture(buf)
+    vp = multiply4(proj_matrix(cam["fx"], cam["fy"], W, H), view_matrix(cam))
+    di, _ = depth_order(buf, vp)
+    col = sh_colors(_f32(xyz)[order], _f32(f_dc)[order], _f32(f_rest)[order], degree, cam["position"])
+    return render_view(tex, di, cam, W, H, override_color=col)

@@ -401,3 +401,57 @@ void gsxo_render_view(int64_t n, const uint32_t* texdata, const uint32_t* depth_
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Spherical-harmonics colour, degrees 0..3 — NOT in the reference (gs.js reads only f_dc, 565-569);
+ * BASELINE.json's config 3 asks for SH degree 3, so the standard 3DGS real-SH basis (Kerbl et al. 2023,
+ * evaluated along dir = normalize(position - camera position)) is restated here.  Parity for this term
+ * is UNPINNED by the reference.  rgb = clamp(0.5 + sum_k basis_k(dir) * coeff_k, 0, 1), fp32.
+ * xyz: n x 3 positions; f_dc: n x 3; f_rest: n x 3*((deg+1)^2-1), channel-major as in a 3DGS PLY
+ * (f_rest_[c*K1 + k-1]); rows are in the SAME order as xyz.  out: n x 4 (alpha slot unused = 0).
+ * ---------------------------------------------------------------------------------------------- */
+void gsxo_sh_colors(int64_t n, const float* xyz, const float* f_dc, const float* f_rest, int32_t deg,
+                    const double campos64[3], float* out) {
+    const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+    const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+    const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                         -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const int K1 = (deg + 1) * (deg + 1) - 1;
+    const float cp[3] = {(float)campos64[0], (float)campos64[1], (float)campos64[2]};
+    for (int64_t i = 0; i < n; ++i) {
+        float dx = xyz[3 * i] - cp[0], dy = xyz[3 * i + 1] - cp[1], dz = xyz[3 * i + 2] - cp[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float x = dx / len, y = dy / len, z = dz / len;
+        float b[16];
+        b[0] = C0;
+        if (deg > 0) {
+            b[1] = -C1 * y;
+            b[2] = C1 * z;
+            b[3] = -C1 * x;
+        }
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        if (deg > 1) {
+            b[4] = C2[0] * xy;
+            b[5] = C2[1] * yz;
+            b[6] = C2[2] * (2.0f * zz - xx - yy);
+            b[7] = C2[3] * xz;
+            b[8] = C2[4] * (xx - yy);
+        }
+        if (deg > 2) {
+            b[9] = C3[0] * y * (3.0f * xx - yy);
+            b[10] = C3[1] * xy * z;
+            b[11] = C3[2] * y * (4.0f * zz - xx - yy);
+            b[12] = C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+            b[13] = C3[4] * x * (4.0f * zz - xx - yy);
+            b[14] = C3[5] * z * (xx - yy);
+            b[15] = C3[6] * x * (xx - 3.0f * yy);
+        }
+        for (int c = 0; c < 3; ++c) {
+            float acc = b[0] * f_dc[3 * i + c];
+            for (int k = 1; k <= K1; ++k) acc += b[k] * f_rest[(size_t)i * 3 * K1 + (size_t)c * K1 + (k - 1)];
+            acc += 0.5f;
+            out[4 * i + c] = acc < 0.0f ? 0.0f : (acc > 1.0f ? 1.0f : acc);
+        }
+        out[4 * i + 3] = 0.0f;
+    }
+}

@@ -58,3 +58,21 @@ def test_golden_scene_renders_finite_and_front_to_back(g):
     img = oracle.render_view(g["texdata"], g["depth_index"][0], cam, 640, 360)
     assert np.isfinite(img).all() and img[..., 3].max() <= 1.0 + 1e-6 and img[..., 3].max() > 0.5
     assert (img[..., :3] <= img[..., 3:4] + 1e-6).all()          # premultiplied colour never exceeds alpha
+
+
+def test_sh_colour_known_answers():
+    """SH basis sanity (unpinned by the reference): degree 0 is 0.5 + C0*dc; band 1 along +z adds C1*coef[k=2]."""
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    xyz = np.array([[0, 0, 2.0], [0, 0, 2.0]], np.float32)
+    dc = np.array([[0.3, -0.2, 4.0], [0.0, 0.0, -4.0]], np.float32)
+    col0 = oracle.sh_colors(xyz, dc, None, 0, [0, 0, 0])
+    assert np.allclose(col0[:, :3], np.clip(0.5 + C0 * dc, 0, 1), atol=1e-6)
+    rest = np.zeros((2, 9), np.float32)                 # degree 1: 3 coefficients per channel, channel-major
+    rest[0, 0 * 3 + 1] = 0.5                            # red, k = 2 (the z basis function)
+    rest[1, 1 * 3 + 0] = 0.7                            # green, k = 1 (the y basis function): no effect along +z
+    col1 = oracle.sh_colors(xyz, dc, rest, 1, [0, 0, 0])
+    assert np.isclose(col1[0, 0], 0.5 + C0 * 0.3 + C1 * 0.5, atol=1e-6)
+    assert np.allclose(col1[1, :3], col0[1, :3], atol=1e-6)
+    # view dependence: flipping the camera to the other side flips the sign of the band-1 term
+    col1b = oracle.sh_colors(xyz, dc, rest, 1, [0, 0, 4.0])
+    assert np.isclose(col1b[0, 0], 0.5 + C0 * 0.3 - C1 * 0.5, atol=1e-6)
