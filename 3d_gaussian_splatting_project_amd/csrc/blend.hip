@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
                                                               const float4* __restrict__ rec1,
                                                               const float2* __restrict__ rec2, int W, int H, int tiles_x,
                                                               const int* __restrict__ dropped, long long n,
+                                                              unsigned long long* __restrict__ consumed,
                                                               float4* __restrict__ image) {
     __shared__ float4 s0[kBlendThreads];
     __shared__ float4 s1[kBlendThreads];
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     const float fyp = (float)H - ((float)py + 0.5f);  // window y is up; image row py counts from the top
     Accum acc{0.f, 0.f, 0.f, 0.f};                    // gl.clear to (0,0,0,0), gs.js:1608
     const int2 range = ranges[tile];
+    int staged = 0;  // list entries this tile actually read
     for (int base = range.x; base < range.y; base += kBlendThreads) {
         const int cnt = min(kBlendThreads, range.y - base);
         __syncthreads();
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
         }
         __syncthreads();
         for (int k = 0; k < cnt; ++k) blend_one(acc, fxp, fyp, s0[k], s1[k], s2[k]);
+        staged += cnt;
         // every further fragment is weighted by (1 - dst.a): once that is < 1e-5 on the whole tile the
         // rest of the list changes no channel by more than 1e-5 (the parity tolerance is 1e-4)
         if (__syncthreads_and(!inside || acc.a > 1.0f - 1.0e-5f)) break;
@@ -80,14 +83,16 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
         for (int k = 0; k < nd; ++k) blend_one(acc, fxp, fyp, r0, r1, r2);
     }
     if (inside) image[(size_t)py * W + px] = make_float4(acc.r, acc.g, acc.b, acc.a);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
 }
 
-int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev) {
+int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
+                 unsigned long long* consumed_dev) {
     const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
     ProfScope ps(c, "render_blend");
     hipLaunchKernelGGL(blend_kernel, dim3(tiles_x * tiles_y), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), vals,
                        c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                       (long long)c->rn, c->r_image.as<float4>());
+                       (long long)c->rn, consumed_dev, c->r_image.as<float4>());
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }

@@ -74,7 +74,7 @@ struct alignas(16) ViewDesc {
     long long seg_off;      // byte offset of this view's u8 map in the seg pool
     int seg_w, seg_h;
     int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
-    int pad_;
+    int seg_tw;      // 16x8 tiles per map row (0: row-major map)
 };
 
 struct ProfEvent {
@@ -99,6 +99,7 @@ struct Ctx {
     int opt_spatial_sort = 1;  // Morton-order the Gaussians at upload (results do not depend on it)
     int opt_xcd_swizzle = 1;   // consecutive logical workgroups share an XCD (its L2)
     int opt_vote_unroll = 4;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
+    int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
 
     // vote
     bool vote_begun = false;
@@ -133,6 +134,8 @@ struct Ctx {
     DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
     int r_sorted_in = 0;
     uint32_t r_P = 0;                    // (tile, splat) pairs of the last view
+    unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)
+    DevBuf r_d0, r_d1, r_d2, r_d3;       // level-1 sort ping-pong (bucket, splat)
 
     // profiling
     bool prof_on = false;

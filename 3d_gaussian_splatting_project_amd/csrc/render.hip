@@ -5,8 +5,8 @@
 //                                   generateTexture    gs.js:301-354  (4*Sigma as truncated fp16)
 //   depth_kernel / preprocess       runSort            gs.js:432-447  (depth int, 16-bit bucket)
 //                                   vertex shader      gs.js:696-750  (fp32, no contraction)
-//   bin / sort / ranges             the global stable counting sort (gs.js:450-457) becomes a stable
-//                                   radix sort of (tile << 17 | bucket) keys: per tile the same order
+//   bin / sort / ranges             the global stable counting sort (gs.js:450-457) becomes two stable
+//                                   radix sorts: splats by bucket, then (tile, splat) pairs by tile
 //   blend.hip                       fragment shader + blend unit gs.js:782-799, 1036-1038
 // This TU is compiled with -ffp-contract=off: JS never fuses, and the vertex stage must produce
 // bit-identical axes to the oracle so that the fragment `discard` (A < -4) decides identically.
@@ -15,7 +15,7 @@
 //   tex        uint4[2n]   the viewer's RGBA32UI texel pairs: [x y z label][h01 h23 h45 rgba8], importance order
 //   buffer     u8[32n]     the viewer's .splat rows (pos, exp(scale), rgba8, quat8)
 //   rec0/1/2   float4,float4,float2 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a)
-//   keys/vals  u32[P]      (tile << 17 | bucket, splat) pairs, P = sum of tiles touched
+//   keys/vals  u32[P]      (tile, splat) pairs emitted in depth order, P = sum of tiles touched
 //   ranges     int2[tiles] [start, end) into the sorted pairs
 #include <hip/hip_runtime.h>
 
@@ -236,16 +236,18 @@ struct ViewUniforms {
 };
 
 // depth = ((vp[2]*x + vp[6]*y + vp[10]*z) * 4096) | 0 and its min / max  (gs.js:436-441)
+// grid-stride over the splats; one atomic pair per workgroup (same-address atomics serialise in L2)
 __global__ __launch_bounds__(kRB) void depth_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
                                                      int* __restrict__ depth, int* __restrict__ minmax) {
-    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
-    int d = 0, lo = 2147483647, hi = -2147483647 - 1;
-    if (i < n) {
+    __shared__ int slo[4], shi[4];
+    int lo = 2147483647, hi = -2147483647 - 1;
+    for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
         const uint4 t = tex[2 * i];
         const double x = (double)__uint_as_float(t.x), y = (double)__uint_as_float(t.y), z = (double)__uint_as_float(t.z);
-        d = js_toint32((u.vp2 * x + u.vp6 * y + u.vp10 * z) * 4096.0);
+        const int d = js_toint32((u.vp2 * x + u.vp6 * y + u.vp10 * z) * 4096.0);
         depth[i] = d;
-        lo = hi = d;
+        lo = min(lo, d);
+        hi = max(hi, d);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -253,8 +255,13 @@ __global__ __launch_bounds__(kRB) void depth_kernel(const uint4* __restrict__ te
         hi = max(hi, __shfl_xor(hi, o));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&minmax[0], lo);
-        atomicMax(&minmax[1], hi);
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&minmax[0], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
+        atomicMax(&minmax[1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
     }
 }
 
@@ -431,21 +438,37 @@ __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restri
     }
 }
 
-// ---- emit (tile << 17 | bucket, splat) pairs, in splat order (stability of the later sort) --------------------
-__global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* __restrict__ tile_rect,
-                                                    const uint32_t* __restrict__ tile_count,
-                                                    const uint32_t* __restrict__ offset, const uint32_t* __restrict__ bucket,
-                                                    int tiles_x, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (i >= n || tile_count[i] == 0) return;
+// ---- two-level ordering ------------------------------------------------------------------------------
+// The reference orders ALL splats by (bucket, index) (stable counting sort, gs.js:450-457).  Level 1 sorts
+// the n splats by bucket (17 bits, stable); level 2 emits their (tile, splat) pairs in that order and
+// sorts the P pairs by tile only (stable): inside a tile the pairs keep the (bucket, index) order.
+__global__ __launch_bounds__(kRB) void iota2_kernel(uint32_t* __restrict__ idx, long long n) {
+    const long long r = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (r < n) idx[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(kRB) void gather_count_kernel(const uint32_t* __restrict__ by_depth, long long n,
+                                                            const uint32_t* __restrict__ tile_count,
+                                                            uint32_t* __restrict__ out) {
+    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (j < n) out[j] = tile_count[by_depth[j]];
+}
+
+__global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* __restrict__ by_depth,
+                                                    const uint32_t* __restrict__ tile_rect,
+                                                    const uint32_t* __restrict__ count_sorted,
+                                                    const uint32_t* __restrict__ offset, int tiles_x,
+                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
+    if (j >= n || count_sorted[j] == 0) return;
+    const uint32_t i = by_depth[j];
     const uint32_t rect = tile_rect[i];
     const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
-    uint32_t o = offset[i];
-    const uint32_t b = bucket[i];
+    uint32_t o = offset[j];
     for (uint32_t ty = ty0; ty <= ty1; ++ty)
         for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-            keys[o] = ((ty * (uint32_t)tiles_x + tx) << 17) | b;
-            vals[o] = (uint32_t)i;
+            keys[o] = ty * (uint32_t)tiles_x + tx;
+            vals[o] = i;
             ++o;
         }
 }
@@ -454,9 +477,9 @@ __global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict_
                                                       int2* __restrict__ ranges) {
     const long long p = (long long)blockIdx.x * kRB + threadIdx.x;
     if (p >= P) return;
-    const uint32_t t = keys[p] >> 17;
-    if (p == 0 || (keys[p - 1] >> 17) != t) ranges[t].x = (int)p;
-    if (p == P - 1 || (keys[p + 1] >> 17) != t) ranges[t].y = (int)(p + 1);
+    const uint32_t t = keys[p];
+    if (p == 0 || keys[p - 1] != t) ranges[t].x = (int)p;
+    if (p == P - 1 || keys[p + 1] != t) ranges[t].y = (int)(p + 1);
 }
 
 // ---- host drivers -----------------------------------------------------------------------------------------
@@ -588,14 +611,15 @@ int upload_sh(Ctx* c, const float* f_rest, int deg) {
     return GSX_OK;
 }
 
-int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev);  // blend.hip
+int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
+                 unsigned long long* consumed_dev);  // blend.hip
 
 int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, hipSetDevice(c->device));
     if (!cam || W < 1 || H < 1) return fail(c, GSX_E_INVALID, "render_view: bad arguments");
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
-    if (tiles_x > 256 || tiles_y > 256 || (long long)tiles_x * tiles_y > 32767)
-        return fail(c, GSX_E_UNSUPPORTED, "render_view: %dx%d needs more than 32767 16x16 tiles", W, H);
+    if (tiles_x > 256 || tiles_y > 256)
+        return fail(c, GSX_E_UNSUPPORTED, "render_view: %dx%d exceeds 4096 pixels per side", W, H);
     const long long n = c->rn;
     const size_t img_bytes = sizeof(float) * 4 * (size_t)W * H;
     GSX_HIP(c, c->r_image.ensure(img_bytes));
@@ -605,8 +629,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)ntiles));
     GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)ntiles, c->stream));
     GSX_HIP(c, c->r_small.ensure(64));
-    int* minmax = c->r_small.as<int>();        // [0]=min [1]=max [2]=dropped [3]=P
-    const int init[4] = {2147483647, -2147483647 - 1, 0, 0};
+    int* minmax = c->r_small.as<int>();        // [0]=min [1]=max [2]=dropped [3]=P [4..5]=pairs consumed by blend (u64)
+    const int init[6] = {2147483647, -2147483647 - 1, 0, 0, 0, 0};
     GSX_HIP(c, hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, c->stream));
     c->r_P = 0;
     if (n > 0) {
@@ -647,7 +671,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         }
         {
             ProfScope ps(c, "render_depth");
-            hipLaunchKernelGGL(depth_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
+            hipLaunchKernelGGL(depth_kernel, dim3(std::min<unsigned>(grid_for(n), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_depth.as<int>(), minmax);
         }
         {
@@ -658,7 +682,23 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                                c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2);
         }
         GSX_HIP(c, hipGetLastError());
-        int rc = exclusive_scan_u32(c, c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), n, (uint32_t*)(minmax + 3));
+        // level 1: splats by depth bucket (stable)
+        GSX_HIP(c, c->r_d0.ensure(n4));
+        GSX_HIP(c, c->r_d1.ensure(n4));
+        GSX_HIP(c, c->r_d2.ensure(n4));
+        GSX_HIP(c, c->r_d3.ensure(n4));
+        GSX_HIP(c, hipMemcpyAsync(c->r_d0.p, c->r_bucket.p, n4, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(iota2_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_d1.as<uint32_t>(), n);
+        int dwhere = 0;
+        int rc = radix_sort_pairs(c, c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_d2.as<uint32_t>(), c->r_d3.as<uint32_t>(),
+                                  n, 17, &dwhere);
+        if (rc) return rc;
+        const uint32_t* by_depth = dwhere ? c->r_d3.as<uint32_t>() : c->r_d1.as<uint32_t>();
+        uint32_t* count_sorted = dwhere ? c->r_d0.as<uint32_t>() : c->r_d2.as<uint32_t>();  // the free key buffer
+        hipLaunchKernelGGL(gather_count_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, by_depth, n,
+                           c->r_count.as<uint32_t>(), count_sorted);
+        GSX_HIP(c, hipGetLastError());
+        rc = exclusive_scan_u32(c, count_sorted, c->r_offset.as<uint32_t>(), n, (uint32_t*)(minmax + 3));
         if (rc) return rc;
         uint32_t P = 0;
         GSX_HIP(c, hipMemcpyAsync(&P, minmax + 3, 4, hipMemcpyDeviceToHost, c->stream));
@@ -671,16 +711,16 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             GSX_HIP(c, c->r_vals1.ensure(4 * (size_t)P));
             {
                 ProfScope ps(c, "render_emit");
-                hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, n, c->r_rect.as<uint32_t>(),
-                                   c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), c->r_bucket.as<uint32_t>(), tiles_x,
-                                   c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>());
+                hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, n, by_depth, c->r_rect.as<uint32_t>(),
+                                   count_sorted, c->r_offset.as<uint32_t>(), tiles_x, c->r_keys0.as<uint32_t>(),
+                                   c->r_vals0.as<uint32_t>());
             }
             GSX_HIP(c, hipGetLastError());
             int tile_bits = 1;
             while ((1 << tile_bits) < ntiles) ++tile_bits;
             int where = 0;
             rc = radix_sort_pairs(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
-                                  c->r_vals1.as<uint32_t>(), P, 17 + tile_bits, &where);
+                                  c->r_vals1.as<uint32_t>(), P, tile_bits, &where);
             if (rc) return rc;
             c->r_sorted_in = where;
             {
@@ -692,10 +732,13 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             GSX_HIP(c, hipGetLastError());
         }
     }
-    int rc = launch_blend(c, W, H, tiles_x, tiles_y, minmax + 2);
+    int rc = launch_blend(c, W, H, tiles_x, tiles_y, minmax + 2, reinterpret_cast<unsigned long long*>(minmax + 4));
     if (rc) return rc;
+    unsigned long long consumed = 0;
+    GSX_HIP(c, hipMemcpyAsync(&consumed, minmax + 4, 8, hipMemcpyDeviceToHost, c->stream));
     if (rgba_out) GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
+    c->r_consumed = consumed;
     return GSX_OK;
 }
 

@@ -8,7 +8,9 @@
 // Data layout in HBM
 //   positions      SoA  x[n], y[n], z[n] f32                      (coalesced 4 B/lane loads)
 //   views          ViewDesc[V], 192 B each, wave-uniform -> scalar loads, operands live in SGPRs
-//   seg pool       u8 maps, value = label+1 (bin index), one after another; 1 B gathers
+//   seg pool       u8 maps, value = label+1 (bin index), one after another, each stored as 16x8-pixel
+//                  tiles of 128 B (one L2 line): the pixels a wave gathers are a compact patch, so they
+//                  fall into few lines; 1 B gathers
 //   planes         cnt[bins][n_pad], fv[bins][n_pad]  u8 (total_views <= 255) or u16: bin-major so
 //                  that a wave's 64 Gaussians touch 64 consecutive elements of a row
 //   keys, labels   int32[n_pad]
@@ -63,6 +65,8 @@ __device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, dou
         xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
         yi = ys > (double)(vd.seg_h - 1) ? vd.seg_h - 1 : (int)ys;  // :286
     }
+    if (vd.seg_tw)  // 16x8-pixel tiles of 128 B: a compact patch of pixels is a compact set of cache lines
+        return vd.seg_off + (((long long)(yi >> 3) * vd.seg_tw + (xi >> 4)) << 7) + ((yi & 7) << 4) + (xi & 15);
     return vd.seg_off + (long long)yi * vd.seg_w + xi;
 }
 
@@ -93,36 +97,32 @@ __device__ __forceinline__ unsigned logical_block(unsigned b, unsigned nwg, int 
 // seg-map packing: int32/int64/u8 host dtype -> u8 bin index (label+1), with range validation
 // -------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ in, uint8_t* __restrict__ out,
-                                                          long long npix, int bins, int* __restrict__ err) {
-    // 4 pixels per thread: 16 B (int32) in, 4 B out per lane
+__global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ in, uint8_t* __restrict__ out, int w,
+                                                          int h, int groups_per_row, int tiles_w, int bins,
+                                                          int* __restrict__ err) {
+    // one thread = 4 horizontally adjacent pixels of one row: 16 B (int32) in, one aligned u32 out
     const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const long long base = q * 4;
-    if (base >= npix) return;
+    const int y = (int)(q / groups_per_row);
+    if (y >= h) return;
+    const int x0 = (int)(q % groups_per_row) * 4;
+    const T* row = in + (long long)y * w;
     int bad = 0;
-    if (base + 4 <= npix) {
-        T v[4];
+    uint32_t packed = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = in[base + k];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long long b = (long long)v[k] + (sizeof(T) == 1 ? 0 : 1);
+    for (int k = 0; k < 4; ++k) {
+        if (x0 + k < w) {
+            const long long b = (long long)row[x0 + k] + (sizeof(T) == 1 ? 0 : 1);
             bad |= (b < 0) | (b >= bins);
             packed |= (uint32_t)(b & 0xff) << (8 * k);
         }
-        if ((reinterpret_cast<uintptr_t>(out) & 3) == 0) {
-            reinterpret_cast<uint32_t*>(out)[q] = packed;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) out[base + k] = (uint8_t)(packed >> (8 * k));
-        }
+    }
+    long long o;
+    if (tiles_w) o = (((long long)(y >> 3) * tiles_w + (x0 >> 4)) << 7) + ((y & 7) << 4) + (x0 & 15);
+    else o = (long long)y * w + x0;
+    if (tiles_w || (((w & 3) == 0))) {
+        *reinterpret_cast<uint32_t*>(out + o) = packed;  // tiled rows are 16 B, maps start 256-B aligned
     } else {
-        for (long long p = base; p < npix; ++p) {
-            const long long b = (long long)in[p] + (sizeof(T) == 1 ? 0 : 1);
-            bad |= (b < 0) | (b >= bins);
-            out[p] = (uint8_t)b;
-        }
+        for (int k = 0; k < 4 && x0 + k < w; ++k) out[o + k] = (uint8_t)(packed >> (8 * k));
     }
     if (bad) atomicOr(err, 1);
 }
@@ -400,7 +400,9 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     const long long npix = (long long)seg_w * seg_h;
     const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
     const size_t off = (c->seg_used + 255) / 256 * 256;  // 256-B aligned maps
-    int rc = pool_reserve(c, off + (size_t)npix);
+    const int tiles_w = c->opt_seg_tiled ? (seg_w + 15) / 16 : 0;
+    const size_t map_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_h + 7) / 8) * 128 : (size_t)npix + 4;
+    int rc = pool_reserve(c, off + map_bytes);
     if (rc) return rc;
     const void* src = seg;
     if (!seg_on_device) {
@@ -409,18 +411,19 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
         src = c->stage.p;
     }
     uint8_t* dst = c->segpool.as<uint8_t>() + off;
-    const unsigned grid = grid_for((npix + 3) / 4);
+    const int groups = (seg_w + 3) / 4;
+    const unsigned grid = grid_for((long long)groups * seg_h);
     {
         ProfScope ps(c, "seg_pack");
         if (seg_dtype == GSX_SEG_I32)
             hipLaunchKernelGGL(seg_pack_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int32_t*)src, dst,
-                               npix, c->bins, c->errflag.as<int>());
+                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
         else if (seg_dtype == GSX_SEG_I64)
             hipLaunchKernelGGL(seg_pack_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int64_t*)src, dst,
-                               npix, c->bins, c->errflag.as<int>());
+                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
         else
             hipLaunchKernelGGL(seg_pack_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const uint8_t*)src, dst,
-                               npix, c->bins, c->errflag.as<int>());
+                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
     }
     GSX_HIP(c, hipGetLastError());
     int bad = 0;
@@ -433,9 +436,10 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     ViewDesc vd;
     fill_view_desc(vd, cam, seg_w, seg_h, img_w, img_h);
     vd.seg_off = (long long)off;
+    vd.seg_tw = tiles_w;
     c->views.push_back(vd);
     c->views_dirty = true;
-    c->seg_used = off + (size_t)npix;
+    c->seg_used = off + map_bytes;
     c->labels_valid = false;
     return GSX_OK;
 }

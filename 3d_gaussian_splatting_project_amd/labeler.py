@@ -193,6 +193,9 @@ class Context:
     def render_num_pairs(self):
         return self._lib.gsx_render_num_pairs(self.h)
 
+    def render_num_pairs_consumed(self):
+        return self._lib.gsx_render_num_pairs_consumed(self.h)
+
     def render_debug(self, buckets=False):
         """(buffer (n,32) u8, order (n,) u32, texdata (8n,) u32[, buckets (n,) u32]) — test hooks."""
         n = self.n_splats

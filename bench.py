@@ -64,10 +64,11 @@ def render_leg(pkg, ctx, args, W, H):
     ctx.render_view(cams[0], W, H, to_host=False)          # warm-up
     ctx.profile(True)
     t0 = time.perf_counter()
-    pairs = 0
+    pairs = consumed = 0
     for cam in cams:
         ctx.render_view(cam, W, H, to_host=False)
         pairs += ctx.render_num_pairs()
+        consumed += ctx.render_num_pairs_consumed()
     ctx.synchronize()
     dt = time.perf_counter() - t0
     names = ["render_sh", "render_depth", "render_preprocess", "scan", "render_emit", "radix_hist", "radix_rowscan",
@@ -76,12 +77,13 @@ def render_leg(pkg, ctx, args, W, H):
     ctx.profile(False)
     P = pairs / len(cams)
     blend_ms = k_ms["render_blend"]
-    # blend: 4 B sorted index + 40 B record per (tile, splat) pair it consumes (upper bound: all pairs) + 16 B/pixel out
-    alg = P * 44.0 + W * H * 16.0
+    # blend: 4 B sorted index + 40 B record per (tile, splat) pair it actually reads + 16 B/pixel out
+    Pc = consumed / len(cams)
+    alg = Pc * 44.0 + W * H * 16.0
     achieved = alg / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else None
     return {"views": len(cams), "splats": n, "sh_degree": 3, "width": W, "height": H,
             "views_per_s": round(len(cams) / dt, 2), "gaussian_views_per_s": round(n * len(cams) / dt, 1),
-            "tile_splat_pairs_per_view": int(P), "kernel_ms_per_view": k_ms,
+            "tile_splat_pairs_per_view": int(P), "pairs_consumed_per_view": int(Pc), "kernel_ms_per_view": k_ms,
             "blend_roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                                "algorithmic_bytes": int(alg),

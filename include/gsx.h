@@ -70,7 +70,9 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "spatial_sort" (default 1)  Morton-order the Gaussians on the GPU at upload: a wave's 64 Gaussians
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
- *   "vote_unroll"  (default 4)  views whose seg-map gathers are in flight together: 1, 2, 4, 8 */
+ *   "vote_unroll"  (default 4)  views whose seg-map gathers are in flight together: 1, 2, 4, 8
+ *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the
+ *                               views staged after the call) */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
 
 /* ---------------------------------------------------------------------------------------------
@@ -170,6 +172,8 @@ int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t 
 void* gsx_render_image_device(gsx_ctx* ctx);
 /* number of (tile, splat) pairs the last gsx_render_view sorted and blended */
 int64_t gsx_render_num_pairs(const gsx_ctx* ctx);
+/* ... and how many of them the blend kernel actually read (a tile stops once it is opaque) */
+int64_t gsx_render_num_pairs_consumed(const gsx_ctx* ctx);
 /* test hooks (any pointer may be NULL): the packed .splat rows (n x 32 bytes) and importance
  * permutation (gs.js:527), the texture words (n x 8 u32, gs.js:311-353) and the last view's 16-bit
  * depth buckets (65536 = dropped by the JS counting sort, gs.js:443-457) */
