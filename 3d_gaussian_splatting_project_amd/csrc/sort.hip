@@ -158,8 +158,13 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
     uint32_t* rowsum = hist + (size_t)256 * ntiles;
     uint32_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
     int where = 0;
-    for (int shift = 0; shift < bits; shift += 8) {
-        const uint32_t mask = (1u << std::min(8, bits - shift)) - 1u;  // key bits >= `bits` never take part
+    // passes of (almost) equal width <= 8 bits: 13 bits -> 7+6, 17 -> 6+6+5, 30 -> 8+8+7+7.  Narrower
+    // digits mean fewer, longer runs per workgroup in the scatter.
+    const int passes = (bits + 7) / 8;
+    int shift = 0;
+    for (int pass = 0; pass < passes; ++pass) {
+        const int width = (bits - shift + (passes - pass) - 1) / (passes - pass);
+        const uint32_t mask = (1u << width) - 1u;  // key bits >= `bits` never take part
         {
             ProfScope ps(c, "radix_hist");
             hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, shift, mask, hist, ntiles);
@@ -177,6 +182,7 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
         std::swap(ki, ko);
         std::swap(vi, vo);
         where ^= 1;
+        shift += width;
     }
     *result_in = where;
     return GSX_OK;

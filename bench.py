@@ -45,6 +45,8 @@ def parse():
                     help="experiment: pre-sort the Gaussians on the host before upload")
     ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
     ap.add_argument("--render-splats", type=int, default=3_000_000)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend; gloo + several ranks on one GPU is a functional rehearsal only")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
     return ap.parse_args()
@@ -103,10 +105,14 @@ def main():
     pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
     scene = pkg.scene
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
     n, V, W, H = args.gaussians, args.views, args.width, args.height
     total_views = V * world
@@ -125,7 +131,7 @@ def main():
         code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
         pos = np.ascontiguousarray(pos[np.argsort(code, kind="stable")])
     cams_all = scene.make_cameras(total_views, W, H, convention="w2c")
-    ctx = pkg.Context(local_rank)
+    ctx = pkg.Context(device)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))

@@ -20,22 +20,23 @@
 
 // every lane touches its own 128-B line exactly once (a bijection on [0, lines)): lines*1 B useful
 __global__ void gather_lines_kernel(const unsigned char* __restrict__ buf, unsigned long long lines,
-                                    unsigned long long mult, unsigned* __restrict__ sink) {
+                                    unsigned long long mult, unsigned magic, unsigned* __restrict__ sink) {
     const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lines) return;
     const unsigned long long line = (i * mult) % lines;  // mult odd and lines a power of two -> permutation
     const unsigned v = buf[line * 128ull + (i & 127ull)];
-    if (v == 0x12345u) sink[0] = v;  // never true for bytes: keeps the load alive
+    if (v == magic) sink[0] = v;  // magic is a run-time value the buffer never holds: keeps the load alive
 }
 
-__global__ void stream_kernel(const uint4* __restrict__ buf, unsigned long long n16, unsigned* __restrict__ sink) {
+__global__ void stream_kernel(const uint4* __restrict__ buf, unsigned long long n16, unsigned magic,
+                              unsigned* __restrict__ sink) {
     unsigned acc = 0;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
          i += (unsigned long long)gridDim.x * blockDim.x) {
         const uint4 v = buf[i];
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
     }
-    if (acc == 0x12345u) sink[0] = acc;
+    if (acc == magic) sink[0] = acc;
 }
 
 int main() {
@@ -48,9 +49,9 @@ int main() {
     CHECK(hipMemset(buf, 1, bytes));
     CHECK(hipDeviceSynchronize());
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)(lines / 256)), dim3(256), 0, 0, buf, lines, 2654435761ull, sink);
+        hipLaunchKernelGGL(gather_lines_kernel, dim3((unsigned)(lines / 256)), dim3(256), 0, 0, buf, lines, 2654435761ull, 7u, sink);
         CHECK(hipDeviceSynchronize());
-        hipLaunchKernelGGL(stream_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<const uint4*>(buf), bytes / 16, sink);
+        hipLaunchKernelGGL(stream_kernel, dim3(4096), dim3(256), 0, 0, reinterpret_cast<const uint4*>(buf), bytes / 16, 0x12345u, sink);
         CHECK(hipDeviceSynchronize());
     }
     std::printf("gather_lines_kernel: %llu distinct 128-B lines = %llu bytes of lines, %llu useful bytes\n", lines, lines * 128,
