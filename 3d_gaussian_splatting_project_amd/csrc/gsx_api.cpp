@@ -144,6 +144,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     if (k == "spatial_sort") c->opt_spatial_sort = value != 0;
     else if (k == "xcd_swizzle") c->opt_xcd_swizzle = value != 0;
     else if (k == "seg_tiled") c->opt_seg_tiled = value != 0;
+    else if (k == "shared_rcp") c->opt_shared_rcp = value != 0;
     else if (k == "vote_unroll") {
         if (value != 1 && value != 2 && value != 4 && value != 8)
             return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 1, 2, 4 or 8");

@@ -41,14 +41,45 @@ __device__ __forceinline__ double row_dot(const double* __restrict__ Rr, double 
     return __builtin_fma(Rr[2], v2, __builtin_fma(Rr[0], v0, Rr[1] * v1));
 }
 
+// Two IEEE-754 divisions by the same denominator, bit-identical to `ax / b` and `ay / b`.
+// hipcc expands an fp64 division into div_scale(den), rcp, two Newton steps, div_scale(num), mul, fma,
+// div_fmas, div_fixup.  Everything up to the refined reciprocal depends only on the SCALED denominator,
+// which is the same for both quotients unless v_div_scale rescales for an extreme exponent gap; so the
+// reciprocal chain (1 v_rcp_f64 + 4 v_fma_f64) is computed once.  A lane whose two scaled denominators
+// differ takes the plain division (never seen on real data; covered by the edge-case tests).
+__device__ __forceinline__ void div2_shared(double ax, double ay, double b, double& qx, double& qy) {
+    bool unused, vx, vy;
+    const double sdx = __builtin_amdgcn_div_scale(ax, b, false, &unused);
+    const double sdy = __builtin_amdgcn_div_scale(ay, b, false, &unused);
+    const double nsd = -sdx;
+    double r = __builtin_amdgcn_rcp(sdx);
+    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
+    const double snx = __builtin_amdgcn_div_scale(ax, b, true, &vx);
+    const double mx = snx * r;
+    qx = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, mx, snx), r, mx, vx), b, ax);
+    const double sny = __builtin_amdgcn_div_scale(ay, b, true, &vy);
+    const double my = sny * r;
+    qy = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, my, sny), r, my, vy), b, ay);
+    if (__double_as_longlong(sdx) != __double_as_longlong(sdy)) qy = ay / b;
+}
+
 // returns false where the reference returns None (dls.py:72-73, 80-82)
+template <bool SHARED_RCP>
 __device__ __forceinline__ bool project(const ViewDesc& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
     if (!(pc2 > 0.0)) return false;  // `pc2 <= 0` -> None; a NaN depth fails the bounds test below anyway
     const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
     const double pc1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
-    const double px = (vd.fx * pc0) / pc2 + vd.half_w;  // dls.py:76
-    const double py = (vd.fy * pc1) / pc2 + vd.half_h;  // dls.py:77
+    double qx, qy;
+    if (SHARED_RCP) {
+        div2_shared(vd.fx * pc0, vd.fy * pc1, pc2, qx, qy);
+    } else {
+        qx = (vd.fx * pc0) / pc2;
+        qy = (vd.fy * pc1) / pc2;
+    }
+    const double px = qx + vd.half_w;  // dls.py:76
+    const double py = qy + vd.half_h;  // dls.py:77
     if (!((0.0 <= px) && (px < vd.width) && (0.0 <= py) && (py < vd.height))) return false;  // :80
     xi = (int)px;  // int() truncation, :81
     yi = (int)py;
@@ -56,9 +87,10 @@ __device__ __forceinline__ bool project(const ViewDesc& vd, double X, double Y, 
 }
 
 // byte offset of the voted pixel inside the seg pool, or -1 (dls.py:276-288)
+template <bool SHARED_RCP>
 __device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, double Y, double Z) {
     int xi, yi;
-    if (!project(vd, X, Y, Z, xi, yi)) return -1;
+    if (!project<SHARED_RCP>(vd, X, Y, Z, xi, yi)) return -1;
     if (!vd.unit_scale) {
         const double xs = trunc((double)xi * vd.wscale);  // :281
         const double ys = trunc((double)yi * vd.hscale);  // :282
@@ -70,6 +102,7 @@ __device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, dou
     return vd.seg_off + (long long)yi * vd.seg_w + xi;
 }
 
+template <bool SHARED_RCP>
 __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ z, long long n,
                                                          const ViewDesc* __restrict__ vd,
@@ -78,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int xi, yi;
-    const bool vis = project(*vd, (double)x[i], (double)y[i], (double)z[i], xi, yi);
+    const bool vis = project<SHARED_RCP>(*vd, (double)x[i], (double)y[i], (double)z[i], xi, yi);
     const long long o = perm ? (long long)perm[i] : i;  // back to the caller's order
     ox[o] = vis ? xi : -1;
     oy[o] = vis ? yi : -1;
@@ -144,7 +177,7 @@ struct FusedParams {
     const uint32_t* perm;  // sorted slot -> caller's index, or nullptr
 };
 
-template <int U>
+template <int U, bool SHARED_RCP>
 __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
     uint32_t* row = lds + threadIdx.x * p.stride_dw;
@@ -168,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {  // wave-uniform
-                const long long off = seg_index(p.views[v], X, Y, Z);
+                const long long off = seg_index<SHARED_RCP>(p.views[v], X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -196,7 +229,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 // LDS word per bin: count << 8 | local index of the earliest view that voted it.
 // fv code = FVMAX - global view index of the first vote (larger = earlier; 0 = no vote).
 // -------------------------------------------------------------------------------------------------
-template <int U, typename PT>
+template <int U, typename PT, bool SHARED_RCP>
 __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, PT* __restrict__ cnt,
                                                                    PT* __restrict__ fv, long long n_pad,
                                                                    int view_base, int fresh) {
@@ -220,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {
-                const long long off = seg_index(p.views[v], X, Y, Z);
+                const long long off = seg_index<SHARED_RCP>(p.views[v], X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -325,8 +358,12 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
-        hipLaunchKernelGGL(project_kernel, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
-                           dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+        if (c->opt_shared_rcp)
+            hipLaunchKernelGGL(project_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+        else
+            hipLaunchKernelGGL(project_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(x_host, ox.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream);
@@ -533,12 +570,12 @@ int vote_flush(Ctx* c) {
         const int fresh = c->planes_zero ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
-            auto k = vote_fused_planes_kernel<kUnroll, uint16_t>;
+            auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint16_t, true> : vote_fused_planes_kernel<kUnroll, uint16_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint16_t>(),
                                c->fv.as<uint16_t>(), (long long)c->n_pad, view_base, fresh);
         } else {
-            auto k = vote_fused_planes_kernel<kUnroll, uint8_t>;
+            auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint8_t, true> : vote_fused_planes_kernel<kUnroll, uint8_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint8_t>(),
                                c->fv.as<uint8_t>(), (long long)c->n_pad, view_base, fresh);
@@ -617,10 +654,11 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
             p.stride_dw = odd_dwords(c->bins);
             const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-            auto k = c->opt_vote_unroll == 1   ? vote_fused_labels_kernel<1>
-                     : c->opt_vote_unroll == 2 ? vote_fused_labels_kernel<2>
-                     : c->opt_vote_unroll == 8 ? vote_fused_labels_kernel<8>
-                                               : vote_fused_labels_kernel<4>;
+            const bool sr = c->opt_shared_rcp != 0;
+            auto k = c->opt_vote_unroll == 1   ? (sr ? vote_fused_labels_kernel<1, true> : vote_fused_labels_kernel<1, false>)
+                     : c->opt_vote_unroll == 2 ? (sr ? vote_fused_labels_kernel<2, true> : vote_fused_labels_kernel<2, false>)
+                     : c->opt_vote_unroll == 8 ? (sr ? vote_fused_labels_kernel<8, true> : vote_fused_labels_kernel<8, false>)
+                                               : (sr ? vote_fused_labels_kernel<4, true> : vote_fused_labels_kernel<4, false>);
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->labels.as<int>());

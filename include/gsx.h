@@ -71,6 +71,7 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
  *   "vote_unroll"  (default 4)  views whose seg-map gathers are in flight together: 1, 2, 4, 8
+ *   "shared_rcp"   (default 1)  the two IEEE divisions of a projection share one reciprocal chain
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the
  *                               views staged after the call) */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);

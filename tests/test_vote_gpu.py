@@ -74,7 +74,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     sizes = [(480, 270)] * 9
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 1, "seg_tiled": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
-                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
+                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "shared_rcp": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -90,6 +90,30 @@ def test_results_do_not_depend_on_tuning_options(gsx):
             sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 0, 9)
             cnt, fv = c.debug_planes(151)
             assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
+
+
+def test_project_extreme_exponents(gsx):
+    """Exponent gaps that make v_div_scale rescale one quotient but not the other: the shared-reciprocal
+    division must fall back to the plain IEEE division lane by lane and still equal the oracle."""
+    rng = np.random.default_rng(3)
+    n = 40_000
+    base = rng.normal(size=(n, 3))
+    expo = rng.integers(-38, 38, size=(n, 1))
+    pos = (base * 10.0 ** expo).astype(np.float32)
+    pos[: n // 4, 2] = np.abs(pos[: n // 4, 2]) * np.float32(1e-30) + np.float32(1e-38)     # tiny positive depth
+    R = np.eye(3).tolist()
+    cams = []
+    for fx, fy, p in ((1e-300, 1e300, [0, 0, 0]), (1e300, 1e-300, [0, 0, -1e-30]), (3e150, 2e-160, [1e-20, -1e20, -1e-35]),
+                      (1000.0, 1e-310, [0, 0, -1e-300]), (5e-324, 1e308, [0, 0, -1e-40])):
+        cams.append({"fx": fx, "fy": fy, "width": 1920, "height": 1080, "rotation": R, "position": p})
+    for shared in (1, 0):
+        with gsx.Context(0) as c:
+            c.set_option("shared_rcp", shared)
+            c.upload_positions(pos)
+            for cam in cams:
+                x, y = c.project_all(cam)
+                ox, oy = oracle.project_many(pos, cam)
+                assert np.array_equal(x, ox) and np.array_equal(y, oy), (shared, cam["fx"], cam["fy"])
 
 
 # ---- assign_labels ---------------------------------------------------------------------------------
