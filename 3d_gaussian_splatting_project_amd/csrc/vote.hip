@@ -205,11 +205,18 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
                 if (off >= 0) bin[u] = pool[off];
             }
         }
+        // one LDS round trip for the whole chunk: read the U counters first, resolve repeats of a bin
+        // inside the chunk in registers, then apply the votes in (reverse view) order
+        int old[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (int)h[bin[u]] : 0;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (bin[u] >= 0) {
-                const int c = h[bin[u]] + 1;  // dls.py:295
-                h[bin[u]] = (uint8_t)c;
+                int c = old[u] + 1;  // dls.py:295
+#pragma unroll
+                for (int w = 0; w < u; ++w) c += (bin[w] == bin[u]) ? 1 : 0;
+                h[bin[u]] = (uint8_t)c;  // LDS stores of one wave retire in order: the last repeat wins
                 if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
                     bestc = c;
                     best = bin[u];
@@ -657,8 +664,8 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             const bool sr = c->opt_shared_rcp != 0;
             auto k = c->opt_vote_unroll == 1   ? (sr ? vote_fused_labels_kernel<1, true> : vote_fused_labels_kernel<1, false>)
                      : c->opt_vote_unroll == 2 ? (sr ? vote_fused_labels_kernel<2, true> : vote_fused_labels_kernel<2, false>)
-                     : c->opt_vote_unroll == 8 ? (sr ? vote_fused_labels_kernel<8, true> : vote_fused_labels_kernel<8, false>)
-                                               : (sr ? vote_fused_labels_kernel<4, true> : vote_fused_labels_kernel<4, false>);
+                     : c->opt_vote_unroll == 4 ? (sr ? vote_fused_labels_kernel<4, true> : vote_fused_labels_kernel<4, false>)
+                                               : (sr ? vote_fused_labels_kernel<8, true> : vote_fused_labels_kernel<8, false>);
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->labels.as<int>());

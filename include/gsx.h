@@ -70,8 +70,9 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "spatial_sort" (default 1)  Morton-order the Gaussians on the GPU at upload: a wave's 64 Gaussians
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
- *   "vote_unroll"  (default 4)  views whose seg-map gathers are in flight together: 1, 2, 4, 8
- *   "shared_rcp"   (default 1)  the two IEEE divisions of a projection share one reciprocal chain
+ *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 1, 2, 4, 8
+ *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
+ *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the
  *                               views staged after the call) */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
