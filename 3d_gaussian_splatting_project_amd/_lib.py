@@ -77,6 +77,8 @@ _SIGS = {
     "gsx_render_image_device": (C.c_void_p, [C.c_void_p]),
     "gsx_render_num_pairs": (C.c_int64, [C.c_void_p]),
     "gsx_render_num_pairs_consumed": (C.c_int64, [C.c_void_p]),
+    "gsx_hit_test": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_int32),
+                               C.POINTER(C.c_int64)]),
     "gsx_render_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4),
     "gsx_ply_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "gsx_ply_close": (None, [C.c_void_p]),

@@ -326,6 +326,11 @@ int64_t gsx_render_num_pairs_consumed(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
     return c ? (int64_t)c->r_consumed : 0;
 }
+int gsx_hit_test(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, double x, double y,
+                 int32_t* label_out, int64_t* index_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::hit_test(c, cam, width, height, x, y, label_out, index_out);
+}
 int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uint32_t* texdata_out,
                      uint32_t* bucket_out) {
     CTX_OR_FAIL(ctx);

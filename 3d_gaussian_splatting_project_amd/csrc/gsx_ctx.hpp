@@ -176,6 +176,7 @@ int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const
                   const float* f_dc, const int32_t* labels);
 int upload_sh(Ctx* c, const float* f_rest, int deg);
 int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out);
+int hit_test(Ctx* c, const gsx_camera* cam, int W, int H, double x, double y, int32_t* label_out, int64_t* index_out);
 int render_debug(Ctx* c, uint8_t* buffer_out, uint32_t* order_out, uint32_t* tex_out, uint32_t* bucket_out);
 void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);
 

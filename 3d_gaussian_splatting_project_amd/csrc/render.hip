@@ -14,7 +14,7 @@
 // HBM layout
 //   tex        uint4[2n]   the viewer's RGBA32UI texel pairs: [x y z label][h01 h23 h45 rgba8], importance order
 //   buffer     u8[32n]     the viewer's .splat rows (pos, exp(scale), rgba8, quat8)
-//   rec0/1/2   float4,float4,float2 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a)
+//   rec0/1/2   3 x float4 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a, bbox ex, ey)
 //   keys/vals  u32[P]      (tile, splat) pairs emitted in depth order, P = sum of tiles touched
 //   ranges     int2[tiles] [start, end) into the sorted pairs
 #include <hip/hip_runtime.h>
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
                                                           const int* __restrict__ depth, const int* __restrict__ minmax,
                                                           const float* __restrict__ sh_rgb /* n x 3 or null */,
                                                           float4* __restrict__ rec0, float4* __restrict__ rec1,
-                                                          float2* __restrict__ rec2, uint32_t* __restrict__ bucket,
+                                                          float4* __restrict__ rec2, uint32_t* __restrict__ bucket,
                                                           uint32_t* __restrict__ tile_rect, uint32_t* __restrict__ tile_count,
                                                           int* __restrict__ dropped) {
     const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
     const float clip = 1.2f * p2[3];
     bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    float2 r2 = make_float2(0.f, 0.f);
+    float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (drawn) {
         const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
         const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
@@ -346,9 +346,9 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
         if (drawn) {
             r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
             r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
-            r2 = make_float2(col[2], col[3]);
             // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
             const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
+            r2 = make_float4(col[2], col[3], ex, ey);
             const float top = u.H - wcy;  // image row coordinate of the centre
             int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
             int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
@@ -660,7 +660,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_offset.ensure(n4));
         GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
         GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
-        GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
+        GSX_HIP(c, c->r_rec2.ensure(16 * (size_t)n));
         c->r_sh_valid = false;
         if (c->r_sh_on) {
             ProfScope ps(c, "render_sh");
@@ -678,7 +678,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             ProfScope ps(c, "render_preprocess");
             hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_depth.as<int>(), minmax, c->r_sh_valid ? c->r_sh.as<float>() : nullptr,
-                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), c->r_bucket.as<uint32_t>(),
+                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float4>(), c->r_bucket.as<uint32_t>(),
                                c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2);
         }
         GSX_HIP(c, hipGetLastError());
@@ -739,6 +739,141 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     if (rgba_out) GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     c->r_consumed = consumed;
+    return GSX_OK;
+}
+
+// ---- hit test: performHitTesting, gs.js:361-395 -------------------------------------------------------------
+// An arg-min reduction over all splats of the key (dist, depth, index): the sequential JS loop keeps the
+// first splat that is strictly nearer, or equally near and strictly less deep.  fp64, JS operation order.
+struct HitKey {
+    double dist, depth;
+    long long idx;  // -1: none
+};
+
+__device__ __forceinline__ bool hit_better(const HitKey& a, const HitKey& b) {  // a replaces b?
+    if (a.idx < 0) return false;
+    if (b.idx < 0) return true;
+    if (a.dist < b.dist) return true;
+    if (a.dist > b.dist) return false;
+    if (a.depth < b.depth) return true;
+    if (a.depth > b.depth) return false;
+    return a.idx < b.idx;
+}
+
+__device__ __forceinline__ double js_hypot2(double a, double b) {  // V8 Math.hypot for two finite-or-not doubles
+    const double big = __longlong_as_double(0x7ff0000000000000LL);
+    if (fabs(a) == big || fabs(b) == big) return big;
+    if (a != a || b != b) return a + b;
+    const double v0 = fabs(a), v1 = fabs(b);
+    const double mx = v0 > v1 ? v0 : v1;
+    if (mx == 0.0) return 0.0;
+    double sum = 0.0, comp = 0.0;
+    {
+        const double q = v0 / mx;
+        const double summand = (q * q) - comp;
+        const double pre = sum + summand;
+        comp = (pre - sum) - summand;
+        sum = pre;
+    }
+    {
+        const double q = v1 / mx;
+        const double summand = (q * q) - comp;
+        const double pre = sum + summand;
+        comp = (pre - sum) - summand;
+        sum = pre;
+    }
+    return sqrt(sum) * mx;
+}
+
+struct HitUniforms {
+    double m[16];  // proj * view, gs.js:364
+    double x, y, vw, vh;
+};
+
+__device__ __forceinline__ HitKey hit_reduce_block(HitKey k, HitKey* sh /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        HitKey other;
+        other.dist = __shfl_xor(k.dist, o);
+        other.depth = __shfl_xor(k.depth, o);
+        other.idx = __shfl_xor(k.idx, o);
+        if (hit_better(other, k)) k = other;
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = k;
+    __syncthreads();
+    HitKey r = sh[0];
+    for (int w = 1; w < 4; ++w)
+        if (hit_better(sh[w], r)) r = sh[w];
+    return r;
+}
+
+__global__ __launch_bounds__(kRB) void hit_partial_kernel(const uint4* __restrict__ tex, long long n, HitUniforms u,
+                                                           HitKey* __restrict__ partial) {
+    __shared__ HitKey sh[4];
+    HitKey best{0.0, 0.0, -1};
+    for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
+        const uint4 t = tex[2 * i];
+        const double p0 = (double)__uint_as_float(t.x), p1 = (double)__uint_as_float(t.y), p2 = (double)__uint_as_float(t.z);
+        double r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = p0 * u.m[k] + p1 * u.m[k + 4] + p2 * u.m[k + 8] + 1.0 * u.m[k + 12];
+        if (r[3] <= 0.0) continue;  // gs.js:402
+        const double sx = (r[0] / r[3] + 1.0) * 0.5 * u.vw;
+        const double sy = (r[1] / r[3] + 1.0) * 0.5 * u.vh;
+        const double depth = r[2] / r[3];
+        const double dist = js_hypot2(sx - u.x, sy - u.y);
+        if (dist < 10.0) {  // gs.js:387
+            const HitKey k{dist, depth, i};
+            if (hit_better(k, best)) best = k;
+        }
+    }
+    best = hit_reduce_block(best, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = best;
+}
+
+__global__ __launch_bounds__(kRB) void hit_final_kernel(const HitKey* __restrict__ partial, int m,
+                                                         const uint4* __restrict__ tex, long long* __restrict__ out) {
+    __shared__ HitKey sh[4];
+    HitKey best{0.0, 0.0, -1};
+    for (int t = threadIdx.x; t < m; t += kRB)
+        if (hit_better(partial[t], best)) best = partial[t];
+    best = hit_reduce_block(best, sh);
+    if (threadIdx.x == 0) {
+        out[0] = best.idx;
+        out[1] = best.idx >= 0 ? (long long)(int)__uint_as_float(tex[2 * best.idx].w) : -999999LL;  // labelData[i]
+    }
+}
+
+int hit_test(Ctx* c, const gsx_camera* cam, int W, int H, double x, double y, int32_t* label_out, int64_t* index_out) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    if (!cam || W < 1 || H < 1) return fail(c, GSX_E_INVALID, "hit_test: bad arguments");
+    long long res[2] = {-1, -999999};
+    if (c->rn > 0) {
+        HitUniforms u{};
+        double view[16], proj[16];
+        js_view_matrix(cam, view);
+        js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
+        js_multiply4(proj, view, u.m);
+        u.x = x;
+        u.y = y;
+        u.vw = (double)W;
+        u.vh = (double)H;
+        const int blocks = (int)std::min<long long>(1024, (c->rn + kRB - 1) / kRB);
+        GSX_HIP(c, c->r_scan.ensure(sizeof(HitKey) * (size_t)blocks + 16));
+        HitKey* partial = c->r_scan.as<HitKey>();
+        long long* out = reinterpret_cast<long long*>(partial + blocks);
+        {
+            ProfScope ps(c, "hit_test");
+            hipLaunchKernelGGL(hit_partial_kernel, dim3(blocks), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), (long long)c->rn, u,
+                               partial);
+            hipLaunchKernelGGL(hit_final_kernel, dim3(1), dim3(kRB), 0, c->stream, partial, blocks, c->r_tex.as<uint4>(), out);
+        }
+        GSX_HIP(c, hipGetLastError());
+        GSX_HIP(c, hipMemcpyAsync(res, out, sizeof res, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (index_out) *index_out = res[0];
+    if (label_out) *label_out = (int32_t)res[1];
     return GSX_OK;
 }
 

@@ -196,6 +196,14 @@ class Context:
     def render_num_pairs_consumed(self):
         return self._lib.gsx_render_num_pairs_consumed(self.h)
 
+    def hit_test(self, camera, width, height, x, y):
+        """performHitTesting (gs.js:361-395) -> (label or -999999, importance-order row or -1)."""
+        cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
+        label, index = C.c_int32(), C.c_int64()
+        check(self._lib.gsx_hit_test(self.h, C.byref(cam), int(width), int(height), float(x), float(y), C.byref(label),
+                                     C.byref(index)), self.h)
+        return label.value, index.value
+
     def render_debug(self, buckets=False):
         """(buffer (n,32) u8, order (n,) u32, texdata (8n,) u32[, buckets (n,) u32]) — test hooks."""
         n = self.n_splats

@@ -176,6 +176,12 @@ void* gsx_render_image_device(gsx_ctx* ctx);
 int64_t gsx_render_num_pairs(const gsx_ctx* ctx);
 /* ... and how many of them the blend kernel actually read (a tile stops once it is opaque) */
 int64_t gsx_render_num_pairs_consumed(const gsx_ctx* ctx);
+/* Selection hit test — performHitTesting, gs.js:361-395: the label of the splat whose projected centre is
+ * nearest to (x, y) (canvas pixels, y measured from the BOTTOM as the viewer's click handler does,
+ * gs.js:1377-1378) within 10 px, nearer NDC depth breaking exact ties; NO_SELECTION (-999999) if none.
+ * *index_out = importance-order row of that splat or -1.  Uses the splats of gsx_upload_splats. */
+int gsx_hit_test(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, double x, double y,
+                 int32_t* label_out, int64_t* index_out);
 /* test hooks (any pointer may be NULL): the packed .splat rows (n x 32 bytes) and importance
  * permutation (gs.js:527), the texture words (n x 8 u32, gs.js:311-353) and the last view's 16-bit
  * depth buckets (65536 = dropped by the JS counting sort, gs.js:443-457) */

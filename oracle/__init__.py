@@ -303,3 +303,19 @@ def render_scene_sh(xyz, scale, rot, opacity, f_dc, f_rest, degree, cam, W, H):
     di, _ = depth_order(buf, vp)
     col = sh_colors(_f32(xyz)[order], _f32(f_dc)[order], _f32(f_rest)[order], degree, cam["position"])
     return render_view(tex, di, cam, W, H, override_color=col)
+
+
+def hit_test(buffer, labels, cam, W, H, x, y):
+    """performHitTesting for a cameras.json-style camera rendered at W x H -> (label, packed row index)."""
+    buffer = np.ascontiguousarray(buffer, dtype=np.uint8)
+    lab = None if labels is None else np.ascontiguousarray(labels, dtype=np.int32)
+    view = view_matrix(cam)
+    proj = proj_matrix(cam["fx"], cam["fy"], W, H)
+    idx = C.c_int64()
+    f = lib().gsxo_hit_test
+    f.restype = C.c_int32
+    f.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double,
+                  C.c_void_p]
+    label = f(len(buffer), buffer.ctypes.data, _ptr(lab), view.ctypes.data, proj.ctypes.data, float(x), float(y), float(W),
+              float(H), C.addressof(idx))
+    return int(label), int(idx.value)

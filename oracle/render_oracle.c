@@ -455,3 +455,56 @@ void gsxo_sh_colors(int64_t n, const float* xyz, const float* f_dc, const float*
         out[4 * i + 3] = 0.0f;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * performHitTesting, gs.js:361-395 (+ project 397-404): the label of the splat whose projected centre is
+ * nearest to the click (x, y in canvas pixels, y up) within 10 px, nearer depth breaking exact ties.
+ * Math.hypot is V8's (node 12 / V8 7.8, builtins-math.cc): scale by the maximum, Kahan-summed squares.
+ * labels: per PACKED row, or NULL -> NO_SELECTION.  Returns the label, *index_out = winning row or -1.
+ * Pinned by tests/golden/render_js.npz (hit_* arrays, produced under node).
+ * ---------------------------------------------------------------------------------------------- */
+static double js_hypot2(double a, double b) {
+    if (isinf(a) || isinf(b)) return INFINITY;
+    if (isnan(a) || isnan(b)) return NAN;
+    const double v[2] = {fabs(a), fabs(b)};
+    const double max = v[0] > v[1] ? v[0] : v[1];
+    if (max == 0) return 0;
+    double sum = 0, compensation = 0;
+    for (int i = 0; i < 2; ++i) {
+        const double n = v[i] / max;
+        const double summand = (n * n) - compensation;
+        const double preliminary = sum + summand;
+        compensation = (preliminary - sum) - summand;
+        sum = preliminary;
+    }
+    return sqrt(sum) * max;
+}
+
+int32_t gsxo_hit_test(int64_t n, const uint8_t* buffer, const int32_t* labels, const double view[16],
+                      const double proj[16], double x, double y, double vw, double vh, int64_t* index_out) {
+    double m[16];
+    gsxo_multiply4(proj, view, m);
+    double closestDist = INFINITY, closestDepth = INFINITY;
+    int32_t selected = -999999;
+    int64_t idx = -1;
+    for (int64_t i = 0; i < n; ++i) {
+        float f[3];
+        memcpy(f, buffer + 32 * i, 12);
+        const double pos[4] = {f[0], f[1], f[2], 1.0};
+        double r[4];
+        for (int k = 0; k < 4; ++k) r[k] = pos[0] * m[k] + pos[1] * m[k + 4] + pos[2] * m[k + 8] + pos[3] * m[k + 12];
+        if (r[3] <= 0) continue;
+        const double screenX = (r[0] / r[3] + 1) * 0.5 * vw;
+        const double screenY = (r[1] / r[3] + 1) * 0.5 * vh;
+        const double depth = r[2] / r[3];
+        const double dist = js_hypot2(screenX - x, screenY - y);
+        if (dist < 10 && (dist < closestDist || (dist == closestDist && depth < closestDepth))) {
+            closestDist = dist;
+            closestDepth = depth;
+            selected = labels ? labels[i] : -999999;
+            idx = i;
+        }
+    }
+    if (index_out) *index_out = idx;
+    return selected;
+}

@@ -76,3 +76,20 @@ def test_sh_colour_known_answers():
     # view dependence: flipping the camera to the other side flips the sign of the band-1 term
     col1b = oracle.sh_colors(xyz, dc, rest, 1, [0, 0, 4.0])
     assert np.isclose(col1b[0, 0], 0.5 + C0 * 0.3 - C1 * 0.5, atol=1e-6)
+
+
+def test_hit_test_matches_node(g):
+    """performHitTesting through the worker's own 'select' message (704 clicks, incl. clicks exactly on
+    projected centres and 9.999 px away from them)."""
+    _, order = oracle.pack_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"])
+    lab = g["labels"][order]
+    hits = 0
+    for v in range(4):
+        cam = cam_dict(g["cam_fx"][v], g["cam_fy"][v], (0, 0), g["cam_R"][v], g["cam_p"][v])
+        W, H = (int(t) for t in g["cam_wh"][v])
+        xy = g["hit_xy"][v] if v < 3 else g["hit_xy_real"]
+        want = g["hit_labels"][v] if v < 3 else g["hit_labels_real"]
+        for (x, y), w in zip(xy, want):
+            assert oracle.hit_test(g["buffer"], lab, cam, W, H, x, y)[0] == w
+            hits += w != -999999
+    assert hits > 300

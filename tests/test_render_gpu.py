@@ -176,3 +176,29 @@ def test_cli_end_to_end(tmp_path, gsx):
     out = pio.PlyData.read(ply_out)["vertex"]
     assert out.properties == ["x", "y", "z", "opacity", "label"]
     assert np.array_equal(out["label"], want) and np.array_equal(out["x"], pos[:, 0])
+
+
+def test_hit_test_matches_node_and_oracle(ctx, g):
+    ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
+    _, order, _ = ctx.render_debug()
+    lab = g["labels"][order]
+    for v in range(4):
+        cam = golden_cam(g, v)
+        W, H = (int(t) for t in g["cam_wh"][v])
+        xy = g["hit_xy"][v] if v < 3 else g["hit_xy_real"]
+        want = g["hit_labels"][v] if v < 3 else g["hit_labels_real"]
+        for (x, y), w in list(zip(xy, want))[::3]:
+            label, idx = ctx.hit_test(cam, W, H, x, y)
+            assert label == w
+            assert (label, idx) == oracle.hit_test(g["buffer"], lab, cam, W, H, x, y)
+    # a larger scene, clicks on a grid: HIP == oracle incl. the winning row
+    n, W, H = 300_000, 1280, 720
+    xyz = scene.make_positions(n, 4)
+    a = scene.make_splat_attributes(n, 4, sh_degree=0)
+    labels = np.random.default_rng(4).integers(-1, 150, n).astype(np.int32)
+    cam = scene.make_cameras(6, W, H, convention="c2w")[4]
+    ctx.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], labels)
+    buf, order, _ = ctx.render_debug()
+    for x in np.linspace(3, W - 3, 9):
+        for y in np.linspace(3, H - 3, 7):
+            assert ctx.hit_test(cam, W, H, x, y) == oracle.hit_test(buf, labels[order], cam, W, H, x, y)

@@ -52,7 +52,15 @@ for (let ci = 0; ci < cams.length; ci++) {
         out.texwidth = tex.texwidth;
         out.texheight = tex.texheight;
     }
+    // performHitTesting (gs.js:361-395) through the worker's own 'select' message
+    const hits = [];
+    for (const [hx, hy] of (cam.clicks || [])) {
+        posted.length = 0;
+        self.onmessage({data: {type: "select", x: hx, y: hy, viewMatrix: view, projectionMatrix: proj,
+                               viewport: [cam.render_width, cam.render_height]}});
+        hits.push(posted.find((m) => m.type === "selection").label);
+    }
     out.cameras.push({view: Array.from(view), proj: Array.from(proj), viewProj: Array.from(viewProj),
-                      depthIndex: b64(srt.depthIndex)});
+                      depthIndex: b64(srt.depthIndex), hits});
 }
 fs.writeFileSync(outPath, JSON.stringify(out));

@@ -69,8 +69,21 @@ def main():
     cams = scene.make_cameras(3, 640, 360, convention="c2w")
     real = json.load(open("/root/reference/Web_Viewer_Gaussians_Selection/cameras.json"))[0]
     cams.append(real)
+    import oracle
+    buf0, _ = oracle.pack_splats(xyz, attrs["scale"], attrs["rot"], attrs["opacity"], attrs["f_dc"])
     for c in cams:
         c["render_width"], c["render_height"] = (640, 360) if c["width"] == 640 else (1557, 1037)
+        # clicks: a grid over the frame + clicks exactly ON projected centres (dist == 0, depth ties possible)
+        W_, H_ = c["render_width"], c["render_height"]
+        clicks = [[float(gx), float(gy)] for gx in np.linspace(5, W_ - 5, 12) for gy in np.linspace(5, H_ - 5, 8)]
+        m = oracle.multiply4(oracle.proj_matrix(c["fx"], c["fy"], W_, H_), oracle.view_matrix(c))
+        pos = buf0[:, :12].copy().view(np.float32).astype(np.float64)
+        r = pos @ m.reshape(4, 4)[:3] + m.reshape(4, 4)[3]
+        ok = np.nonzero(r[:, 3] > 0)[0][:40]
+        for i in ok:
+            clicks.append([float((r[i, 0] / r[i, 3] + 1) * 0.5 * W_), float((r[i, 1] / r[i, 3] + 1) * 0.5 * H_)])
+            clicks.append([float((r[i, 0] / r[i, 3] + 1) * 0.5 * W_) + 9.999, float((r[i, 1] / r[i, 3] + 1) * 0.5 * H_)])
+        c["clicks"] = clicks
     with tempfile.TemporaryDirectory() as d:
         ply, cj, oj = (os.path.join(d, f) for f in ("in.ply", "cams.json", "out.json"))
         write_3dgs_ply(ply, attrs, labels)
@@ -87,6 +100,8 @@ def main():
                  cam_wh=np.array([[c["render_width"], c["render_height"]] for c in cams], np.int32),
                  view=np.array([c["view"] for c in out["cameras"]]), proj=np.array([c["proj"] for c in out["cameras"]]),
                  viewproj=np.array([c["viewProj"] for c in out["cameras"]]),
+                 hit_xy=np.array([c["clicks"] for c in cams[:3]]), hit_labels=np.array([c["hits"] for c in out["cameras"][:3]], np.int32),
+                 hit_xy_real=np.array(cams[3]["clicks"]), hit_labels_real=np.array(out["cameras"][3]["hits"], np.int32),
                  depth_index=np.stack([np.frombuffer(base64.b64decode(c["depthIndex"]), np.uint32) for c in out["cameras"]]))
     np.savez_compressed(os.path.join(OUT, "render_js.npz"), **store)
     di = store["depth_index"]
