@@ -264,12 +264,17 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
                 if (off >= 0) bin[u] = pool[off];
             }
         }
+        unsigned old[U];  // one LDS round trip per chunk, repeats of a bin resolved in registers
+#pragma unroll
+        for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (unsigned)h[bin[u]] : 0u;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (bin[u] >= 0) {
                 const int v = vb - 1 - u;
-                const unsigned w = h[bin[u]];
-                h[bin[u]] = (uint16_t)(((w & 0xff00u) + 0x100u) | (unsigned)v);  // reverse order: last write = earliest view
+                unsigned cnt = (old[u] >> 8) + 1u;
+#pragma unroll
+                for (int w = 0; w < u; ++w) cnt += (bin[w] == bin[u]) ? 1u : 0u;
+                h[bin[u]] = (uint16_t)((cnt << 8) | (unsigned)v);  // reverse order: the last store = the earliest view
             }
         }
     }
@@ -543,7 +548,7 @@ static int set_lds(Ctx* c, K kernel, size_t bytes) {
     return GSX_OK;
 }
 
-static constexpr int kUnroll = 4;
+static constexpr int kUnroll = 8;
 
 // merge views [n_flushed, size) into the planes, kMaxBatch at a time
 int vote_flush(Ctx* c) {
