@@ -4,8 +4,9 @@
 // premultiplied colour) and the blend state of gs.js:1036-1038 (dst += (1 - dst.a) * src, front to
 // back) for one 16x16-pixel tile per workgroup.  The tile's depth-ordered splat list is staged
 // through LDS 256 records at a time (one gather per thread), then every pixel walks the staged records
-// with broadcast LDS reads.  Each of the 4 waves owns an 8x8-pixel quadrant and skips, wave-uniformly,
-// the splats whose bounding box misses its quadrant (most splats are a few pixels wide).  Compiled with -ffp-contract=off: the operations that
+// with broadcast LDS reads.  (A per-wave 8x8-quadrant bounding-box skip was measured: 0.42 ms vs 0.33 ms
+// per 1080p view of the 3 M-splat scene — the pairs that matter come from splats wider than a quadrant,
+// so the test is pure overhead; removed.)  Compiled with -ffp-contract=off: the operations that
 // decide `discard` round exactly like the oracle's; the accumulation uses explicit fmaf.
 #include <hip/hip_runtime.h>
 
@@ -21,7 +22,7 @@ struct Accum {
 };
 
 __device__ __forceinline__ void blend_one(Accum& acc, float fxp, float fyp, const float4 r0, const float4 r1,
-                                          const float4 r2) {
+                                          const float2 r2) {
     const float dx = fxp - r0.x;
     const float dy = fyp - r0.y;
     const float vx = dx * r0.z + dy * r0.w;  // interpolated vPosition (see oracle/render_oracle.c gsxo_vertex)
@@ -41,22 +42,17 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
                                                               const uint32_t* __restrict__ vals,
                                                               const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
-                                                              const float4* __restrict__ rec2, int W, int H, int tiles_x,
+                                                              const float2* __restrict__ rec2, int W, int H, int tiles_x,
                                                               const int* __restrict__ dropped, long long n,
                                                               unsigned long long* __restrict__ consumed,
                                                               float4* __restrict__ image) {
     __shared__ float4 s0[kBlendThreads];
     __shared__ float4 s1[kBlendThreads];
-    __shared__ float4 s2[kBlendThreads];
+    __shared__ float2 s2[kBlendThreads];
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int qx0 = tx * kTile + (wave & 1) * 8, qy0 = ty * kTile + (wave >> 1) * 8;  // this wave's 8x8 quadrant
-    const int px = qx0 + (lane & 7);
-    const int py = qy0 + (lane >> 3);
-    // quadrant centre in GL window coordinates; its pixel centres lie within +-3.5 of it
-    const float qcx = (float)qx0 + 4.0f;
-    const float qcy = (float)H - ((float)qy0 + 4.0f);
+    const int px = tx * kTile + (threadIdx.x & (kTile - 1));
+    const int py = ty * kTile + (threadIdx.x >> 4);
     const bool inside = px < W && py < H;
     const float fxp = (float)px + 0.5f;               // pixel centre, GL window coordinates
     const float fyp = (float)H - ((float)py + 0.5f);  // window y is up; image row py counts from the top
@@ -73,14 +69,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
             s2[threadIdx.x] = rec2[id];
         }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) {
-            const float4 r0 = s0[k];
-            const float4 r2 = s2[k];
-            // r2.z, r2.w: half extents of the splat's bounding box (+1 px of slack, render.hip); the test
-            // is the same in every lane of the wave, so a miss costs one branch
-            if (fabsf(qcx - r0.x) > r2.z + 3.5f || fabsf(qcy - r0.y) > r2.w + 3.5f) continue;
-            blend_one(acc, fxp, fyp, r0, s1[k], r2);
-        }
+        for (int k = 0; k < cnt; ++k) blend_one(acc, fxp, fyp, s0[k], s1[k], s2[k]);
         staged += cnt;
         // every further fragment is weighted by (1 - dst.a): once that is < 1e-5 on the whole tile the
         // rest of the list changes no channel by more than 1e-5 (the parity tolerance is 1e-4)
@@ -92,7 +81,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     if (nd > 0) {
         const float4 r0 = rec0[0];
         const float4 r1 = rec1[0];
-        const float4 r2 = rec2[0];
+        const float2 r2 = rec2[0];
         for (int k = 0; k < nd; ++k) blend_one(acc, fxp, fyp, r0, r1, r2);
     }
     if (inside) image[(size_t)py * W + px] = make_float4(acc.r, acc.g, acc.b, acc.a);
@@ -104,7 +93,7 @@ int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* drop
     const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
     ProfScope ps(c, "render_blend");
     hipLaunchKernelGGL(blend_kernel, dim3(tiles_x * tiles_y), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), vals,
-                       c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float4>(), W, H, tiles_x, dropped_dev,
+                       c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
                        (long long)c->rn, consumed_dev, c->r_image.as<float4>());
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;

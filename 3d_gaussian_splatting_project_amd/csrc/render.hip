@@ -14,7 +14,7 @@
 // HBM layout
 //   tex        uint4[2n]   the viewer's RGBA32UI texel pairs: [x y z label][h01 h23 h45 rgba8], importance order
 //   buffer     u8[32n]     the viewer's .splat rows (pos, exp(scale), rgba8, quat8)
-//   rec0/1/2   3 x float4 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a, bbox ex, ey)
+//   rec0/1/2   float4,float4,float2 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a)
 //   keys/vals  u32[P]      (tile, splat) pairs emitted in depth order, P = sum of tiles touched
 //   ranges     int2[tiles] [start, end) into the sorted pairs
 #include <hip/hip_runtime.h>
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
                                                           const int* __restrict__ depth, const int* __restrict__ minmax,
                                                           const float* __restrict__ sh_rgb /* n x 3 or null */,
                                                           float4* __restrict__ rec0, float4* __restrict__ rec1,
-                                                          float4* __restrict__ rec2, uint32_t* __restrict__ bucket,
+                                                          float2* __restrict__ rec2, uint32_t* __restrict__ bucket,
                                                           uint32_t* __restrict__ tile_rect, uint32_t* __restrict__ tile_count,
                                                           int* __restrict__ dropped) {
     const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
     const float clip = 1.2f * p2[3];
     bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    float4 r2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 r2 = make_float2(0.f, 0.f);
     if (drawn) {
         const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
         const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
             r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
             // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
             const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
-            r2 = make_float4(col[2], col[3], ex, ey);
+            r2 = make_float2(col[2], col[3]);
             const float top = u.H - wcy;  // image row coordinate of the centre
             int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
             int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
@@ -660,7 +660,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_offset.ensure(n4));
         GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
         GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
-        GSX_HIP(c, c->r_rec2.ensure(16 * (size_t)n));
+        GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
         c->r_sh_valid = false;
         if (c->r_sh_on) {
             ProfScope ps(c, "render_sh");
@@ -678,7 +678,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             ProfScope ps(c, "render_preprocess");
             hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_depth.as<int>(), minmax, c->r_sh_valid ? c->r_sh.as<float>() : nullptr,
-                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float4>(), c->r_bucket.as<uint32_t>(),
+                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), c->r_bucket.as<uint32_t>(),
                                c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2);
         }
         GSX_HIP(c, hipGetLastError());

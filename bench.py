@@ -79,9 +79,9 @@ def render_leg(pkg, ctx, args, W, H):
     ctx.profile(False)
     P = pairs / len(cams)
     blend_ms = k_ms["render_blend"]
-    # blend: 4 B sorted index + 48 B record per (tile, splat) pair it actually reads + 16 B/pixel out
+    # blend: 4 B sorted index + 40 B record per (tile, splat) pair it actually reads + 16 B/pixel out
     Pc = consumed / len(cams)
-    alg = Pc * 52.0 + W * H * 16.0
+    alg = Pc * 44.0 + W * H * 16.0
     achieved = alg / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else None
     return {"views": len(cams), "splats": n, "sh_degree": 3, "width": W, "height": H,
             "views_per_s": round(len(cams) / dt, 2), "gaussian_views_per_s": round(n * len(cams) / dt, 1),
