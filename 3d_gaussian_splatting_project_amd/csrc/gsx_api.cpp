@@ -144,6 +144,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     if (k == "spatial_sort") c->opt_spatial_sort = value != 0;
     else if (k == "xcd_swizzle") c->opt_xcd_swizzle = value != 0;
     else if (k == "seg_tiled") c->opt_seg_tiled = value != 0;
+    else if (k == "exchange_slabs") {
+        if (value < 1 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: exchange_slabs must be in [1,64]");
+        c->opt_slabs = (int)value;
+    } else if (k == "exchange_local") c->opt_local_codes = value != 0;
     else if (k == "shared_rcp") c->opt_shared_rcp = value != 0;
     else if (k == "vote_unroll") {
         if (value != 1 && value != 2 && value != 4 && value != 8)
@@ -290,6 +294,24 @@ void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words) {
 int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
     return gsx::vote_labels_from_keys(c, labels_out);
+}
+void* gsx_vote_first_device(gsx_ctx* ctx, int64_t* n_int32_words) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !c->vote_begun) return nullptr;
+    if (n_int32_words) *n_int32_words = (int64_t)c->bins * c->n_pad * (c->wide ? 2 : 1) / 4;
+    return c->fv.p;
+}
+int64_t gsx_vote_slab_size(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return (c && c->vote_begun) ? c->sn : 0;
+}
+int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_slab_reduce(c, recv_counts_dev, recv_first_dev);
+}
+int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_labels_from_sorted(c, sorted_labels_dev, labels_out);
 }
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);

@@ -99,6 +99,8 @@ struct Ctx {
     int opt_spatial_sort = 1;  // Morton-order the Gaussians at upload (results do not depend on it)
     int opt_xcd_swizzle = 1;   // consecutive logical workgroups share an XCD (its L2)
     int opt_vote_unroll = 8;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
+    int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
+    int opt_local_codes = 0;   // see Ctx::local_codes
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_shared_rcp = 0;    // one reciprocal chain for the two IEEE divisions of a projection (measured 2 % slower)
 
@@ -107,6 +109,9 @@ struct Ctx {
     int n_classes = 0, bins = 0;
     int first_view = 0, total_views = 0;
     bool wide = false;  // 16-bit plane counters (total_views > 255)
+    bool local_codes = false;  // planes hold per-rank u8 counters and LOCAL first-view codes (all-to-all exchange)
+    int slabs = 1;             // planes are [slab][bins][sn]; one slab per rank of the all-to-all exchange
+    int64_t sn = 0;            // Gaussians per slab (multiple of 256); n_pad = slabs * sn
     std::vector<ViewDesc> views;
     bool views_dirty = true;  // host views newer than d_views
     DevBuf d_views;
@@ -165,6 +170,8 @@ int vote_flush(Ctx* c);
 int vote_tiebreak_keys(Ctx* c);
 int vote_labels_from_keys(Ctx* c, int32_t* labels_out);
 int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out);
+int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv);
+int vote_labels_from_sorted(Ctx* c, const void* sorted_labels_dev, int32_t* labels_out);
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
                 int32_t* x_host, int32_t* y_host, const uint32_t* perm);
 // sort.hip

@@ -238,8 +238,8 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 // -------------------------------------------------------------------------------------------------
 template <int U, typename PT, bool SHARED_RCP>
 __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, PT* __restrict__ cnt,
-                                                                   PT* __restrict__ fv, long long n_pad,
-                                                                   int view_base, int fresh) {
+                                                                   PT* __restrict__ fv, long long sn,
+                                                                   int view_base, int fresh, int local_codes) {
     constexpr int FVMAX = sizeof(PT) == 1 ? 255 : 65535;
     extern __shared__ uint32_t lds[];
     uint32_t* row = lds + threadIdx.x * p.stride_dw;
@@ -279,11 +279,16 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
         }
     }
     if (!valid) return;
+    // planes are slab-major: [slab][bin][sn] with slab = i / sn (one slab = one rank's share in the
+    // all-to-all exchange; a single slab is the plain [bin][n_pad] layout)
+    const long long slab = i / sn;
+    const long long base = slab * p.bins * sn + (i - slab * sn);
+    const int vb0 = local_codes ? 0 : view_base;  // local codes: 255 - index inside this rank's batch
     for (int b = 0; b < p.bins; ++b) {
         const unsigned w = h[b];
         const unsigned c = w >> 8;
-        const unsigned code = c ? (unsigned)(FVMAX - (view_base + (int)(w & 0xffu))) : 0u;
-        const long long at = (long long)b * n_pad + i;
+        const unsigned code = c ? (unsigned)(FVMAX - (vb0 + (int)(w & 0xffu))) : 0u;
+        const long long at = base + (long long)b * sn;
         if (fresh) {
             cnt[at] = (PT)c;
             fv[at] = (PT)code;
@@ -298,16 +303,18 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
 // per Gaussian: among the bins holding the (global) maximum count, the one this rank saw first
 template <typename PT>
 __global__ __launch_bounds__(kBlock) void vote_keys_kernel(const PT* __restrict__ cnt, const PT* __restrict__ fv,
-                                                           long long n, long long n_pad, int bins,
+                                                           long long n, long long sn, int bins,
                                                            int* __restrict__ keys) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    const long long slab = i / sn;
+    const long long base = slab * bins * sn + (i - slab * sn);
     unsigned M = 0;
     int key = 0;
     for (int b = 0; b < bins; ++b) {
-        const unsigned c = cnt[(long long)b * n_pad + i];
+        const unsigned c = cnt[base + (long long)b * sn];
         if (c == 0 || c < M) continue;
-        const unsigned f = fv[(long long)b * n_pad + i];
+        const unsigned f = fv[base + (long long)b * sn];
         const int k = f ? (int)((f << 8) | (unsigned)b) : 0;
         if (c > M) {
             M = c;
@@ -317,6 +324,44 @@ __global__ __launch_bounds__(kBlock) void vote_keys_kernel(const PT* __restrict_
         }
     }
     keys[i] = key;
+}
+
+// ---- exchange v2: after the all-to-all this rank holds, for ITS slab of Gaussians, every rank's u8 count and
+// first-view planes: recv[r][bin][sn].  Sum the counts, and among the bins holding the maximum pick the one
+// whose first vote is globally earliest: ranks own contiguous, rank-ordered view blocks, so that is the
+// lowest rank that voted it, then its local view code (255 - local index; larger = earlier).
+__global__ __launch_bounds__(kBlock) void vote_slab_reduce_kernel(const uint8_t* __restrict__ rcnt,
+                                                                  const uint8_t* __restrict__ rfv, int S, int bins,
+                                                                  long long sn, int* __restrict__ slab_labels) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= sn) return;
+    unsigned M = 0;
+    int best_bin = -1;
+    unsigned best_key = 0;  // (S - r) << 8 | code : larger = earlier
+    for (int b = 0; b < bins; ++b) {
+        unsigned total = 0;
+        unsigned key = 0;
+        for (int r = 0; r < S; ++r) {
+            const long long at = ((long long)r * bins + b) * sn + i;
+            const unsigned c = rcnt[at];
+            total += c;
+            if (c && key == 0) key = ((unsigned)(S - r) << 8) | (unsigned)rfv[at];
+        }
+        if (total == 0 || total < M) continue;
+        if (total > M || key > best_key) {
+            M = total;
+            best_key = key;
+            best_bin = b;
+        }
+    }
+    slab_labels[i] = best_bin - 1 + (best_bin < 0);  // bin b -> label b-1; never visible -> -1
+}
+
+__global__ __launch_bounds__(kBlock) void unpermute_labels_kernel(const int* __restrict__ sorted, long long n,
+                                                                  const uint32_t* __restrict__ perm,
+                                                                  int* __restrict__ labels) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) labels[perm ? (long long)perm[i] : i] = sorted[i];
 }
 
 __global__ __launch_bounds__(kBlock) void vote_labels_kernel(const int* __restrict__ keys, long long n,
@@ -399,7 +444,12 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->bins = n_classes + 1;
     c->first_view = first_view;
     c->total_views = total_views;
-    c->wide = total_views > 255;
+    c->local_codes = c->opt_local_codes != 0;
+    c->wide = total_views > 255 && !c->local_codes;
+    c->slabs = c->opt_slabs > 0 ? c->opt_slabs : 1;
+    c->sn = ((c->n + c->slabs - 1) / c->slabs + 255) / 256 * 256;
+    if (c->sn == 0) c->sn = 256;
+    c->n_pad = c->sn * c->slabs;
     c->views.clear();
     c->views_dirty = true;
     c->seg_used = 0;
@@ -444,6 +494,9 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
         return fail(c, GSX_E_INVALID, "vote_view: unknown seg_dtype %d", seg_dtype);
     if (c->first_view + (int)c->views.size() >= c->total_views)
         return fail(c, GSX_E_RANGE, "vote_view: more views than total_views=%d announced at vote_begin", c->total_views);
+    if (c->local_codes && (int)c->views.size() >= kMaxBatch)
+        return fail(c, GSX_E_RANGE, "vote_view: the all-to-all exchange keeps 8-bit per-rank counters: at most %d views per rank",
+                    kMaxBatch);
     GSX_HIP(c, hipSetDevice(c->device));
 
     const long long npix = (long long)seg_w * seg_h;
@@ -585,12 +638,12 @@ int vote_flush(Ctx* c) {
             auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint16_t, true> : vote_fused_planes_kernel<kUnroll, uint16_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint16_t>(),
-                               c->fv.as<uint16_t>(), (long long)c->n_pad, view_base, fresh);
+                               c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
             auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint8_t, true> : vote_fused_planes_kernel<kUnroll, uint8_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint8_t>(),
-                               c->fv.as<uint8_t>(), (long long)c->n_pad, view_base, fresh);
+                               c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
         }
         GSX_HIP(c, hipGetLastError());
         c->planes_zero = false;
@@ -611,11 +664,11 @@ int vote_tiebreak_keys(Ctx* c) {
     ProfScope ps(c, "vote_keys");
     if (c->wide)
         hipLaunchKernelGGL(vote_keys_kernel<uint16_t>, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream,
-                           c->cnt.as<uint16_t>(), c->fv.as<uint16_t>(), (long long)c->n, (long long)c->n_pad, c->bins,
+                           c->cnt.as<uint16_t>(), c->fv.as<uint16_t>(), (long long)c->n, (long long)c->sn, c->bins,
                            c->keys.as<int>());
     else
         hipLaunchKernelGGL(vote_keys_kernel<uint8_t>, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream,
-                           c->cnt.as<uint8_t>(), c->fv.as<uint8_t>(), (long long)c->n, (long long)c->n_pad, c->bins,
+                           c->cnt.as<uint8_t>(), c->fv.as<uint8_t>(), (long long)c->n, (long long)c->sn, c->bins,
                            c->keys.as<int>());
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
@@ -684,6 +737,34 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
     return vote_labels_from_keys(c, labels_out);
 }
 
+int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv) {
+    if (!c->vote_begun || !c->local_codes) return fail(c, GSX_E_STATE, "vote_slab_reduce needs vote_begin with the 'exchange_local' option");
+    if (!recv_cnt || !recv_fv) return fail(c, GSX_E_INVALID, "vote_slab_reduce: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)c->n_pad));
+    ProfScope ps(c, "vote_slab_reduce");
+    hipLaunchKernelGGL(vote_slab_reduce_kernel, dim3(grid_for(c->sn)), dim3(kBlock), 0, c->stream, (const uint8_t*)recv_cnt,
+                       (const uint8_t*)recv_fv, c->slabs, c->bins, (long long)c->sn, c->keys.as<int>());
+    GSX_HIP(c, hipGetLastError());
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int vote_labels_from_sorted(Ctx* c, const void* sorted_labels_dev, int32_t* labels_out) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_labels_from_sorted before vote_begin");
+    if (!sorted_labels_dev) return fail(c, GSX_E_INVALID, "vote_labels_from_sorted: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    if (c->n > 0) {
+        ProfScope ps(c, "vote_labels");
+        hipLaunchKernelGGL(unpermute_labels_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream,
+                           (const int*)sorted_labels_dev, (long long)c->n, c->sorted ? c->perm.as<uint32_t>() : nullptr,
+                           c->labels.as<int>());
+        GSX_HIP(c, hipGetLastError());
+    }
+    return labels_to_host(c, labels_out);
+}
+
 int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
     if (!c->vote_begun || !(c->planes_valid || c->planes_zero)) return fail(c, GSX_E_STATE, "vote_debug_planes: no planes");
     if (!counts_out || !first_out) return fail(c, GSX_E_INVALID, "vote_debug_planes: NULL argument");
@@ -702,7 +783,8 @@ int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
         uint16_t* out = which ? first_out : counts_out;
         for (int b = 0; b < c->bins; ++b)
             for (int64_t i = 0; i < c->n; ++i) {
-                const size_t at = (size_t)b * c->n_pad + i;
+                const size_t slab = (size_t)i / (size_t)c->sn;
+                const size_t at = (slab * c->bins + b) * (size_t)c->sn + ((size_t)i - slab * (size_t)c->sn);
                 out[(size_t)b * c->n + (perm.empty() ? (size_t)i : (size_t)perm[i])] = c->wide ? reinterpret_cast<uint16_t*>(tmp.data())[at] : tmp[at];
             }
     }

@@ -82,6 +82,107 @@ def exchange_labels(shard, group=None, to_host=True):
     return shard.labels(to_host)
 
 
+# ---- protocol v2: all-to-all (reduce-scatter by hand) -> local arg-max -> all-gather of labels -------------
+#   1. each rank votes its views into u8 planes laid out [slab][bins][sn] (slab j = rank j's share of the
+#      Gaussians), per-rank counters (<= 255 views per rank) and LOCAL first-view codes
+#   2. all_to_all over the count plane and over the first-view plane: rank j gets [src rank][bins][sn]
+#   3. rank j sums the counters of its slab and breaks ties by (lowest rank, earliest local view)
+#   4. all_gather of the sn int32 labels per rank; back to the caller's order
+# Moves 2*(world-1)/world * bins*n bytes per rank instead of the all-reduce's ~2*(world-1)/world * 2*bins*n
+# (16-bit counters), and the wide histogram crosses xGMI once.
+class GpuSlabShard:
+    """Rank-local state of protocol v2 on the GPU.  The ctx must have been configured with
+    configure_a2a(ctx, world) BEFORE upload/vote_begin."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def planes(self):
+        self.ctx.vote_flush()
+        cp, words = self.ctx.counts_device()
+        fp, _ = self.ctx.first_device()
+        self.ctx.synchronize()
+        dev = self.ctx.device
+        return device_words_tensor(cp, words, dev), device_words_tensor(fp, words, dev)
+
+    def reduce(self, recv_cnt, recv_fv):
+        torch.cuda.synchronize(self.ctx.device)
+        self.ctx.vote_slab_reduce(recv_cnt.data_ptr(), recv_fv.data_ptr())
+        kp, _ = self.ctx.keys_device()
+        return device_words_tensor(kp, self.ctx.slab_size(), self.ctx.device)
+
+    def finish(self, all_labels, to_host=True):
+        torch.cuda.synchronize(self.ctx.device)
+        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host)
+
+
+class HostSlabShard:
+    """Adapter for a numpy-backed slab shard (tests, gloo)."""
+
+    def __init__(self, shard):
+        self.shard = shard
+
+    def planes(self):
+        return torch.from_numpy(self.shard.cnt.reshape(-1).view(np.int32)), torch.from_numpy(self.shard.fv.reshape(-1).view(np.int32))
+
+    def reduce(self, recv_cnt, recv_fv):
+        return torch.from_numpy(self.shard.reduce(recv_cnt.numpy().view(np.uint8), recv_fv.numpy().view(np.uint8)))
+
+    def finish(self, all_labels, to_host=True):
+        return self.shard.finish(all_labels.numpy())
+
+
+def configure_a2a(ctx, world):
+    """Plane layout of protocol v2; call before upload_positions / vote_begin."""
+    ctx.set_option("exchange_slabs", world)
+    ctx.set_option("exchange_local", 1)
+
+
+def _all_to_all(out, inp, group):
+    if dist.get_backend(group) == "gloo":
+        # rehearsal / CPU tests only: gloo has no all_to_all (and no GPU all_gather): stage through the
+        # host, gather everything, keep my column
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        host = inp.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        chunk = inp.numel() // world
+        for r in range(world):
+            out[r * chunk:(r + 1) * chunk] = parts[r][rank * chunk:(rank + 1) * chunk].to(out.device)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def _all_gather_into(full, part, group):
+    if dist.get_backend(group) == "gloo":
+        world = dist.get_world_size(group)
+        host = part.cpu().contiguous()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        full.copy_(torch.cat(parts).to(full.device))
+    else:
+        dist.all_gather_into_tensor(full, part.contiguous(), group=group)
+
+
+def exchange_labels_a2a(shard, group=None, to_host=True):
+    """Steps 2-4 of protocol v2.  `shard` is a GpuSlabShard (RCCL) or HostSlabShard (gloo)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    cnt, fv = shard.planes()
+    if world > 1:
+        rc, rf = torch.empty_like(cnt), torch.empty_like(fv)
+        _all_to_all(rc, cnt, group)
+        _all_to_all(rf, fv, group)
+    else:
+        rc, rf = cnt, fv
+    slab = shard.reduce(rc, rf)
+    if world > 1:
+        full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
+        _all_gather_into(full, slab, group)
+    else:
+        full = slab
+    return shard.finish(full, to_host)
+
+
 def view_range(n_views_total, rank, world):
     """Contiguous, rank-ordered split of the processed camera list."""
     base, rem = divmod(n_views_total, world)

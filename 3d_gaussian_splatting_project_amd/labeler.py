@@ -152,6 +152,23 @@ class Context:
         p = self._lib.gsx_vote_keys_device(self.h, C.byref(n))
         return p, n.value
 
+    def first_device(self):
+        n = C.c_int64()
+        p = self._lib.gsx_vote_first_device(self.h, C.byref(n))
+        return p, n.value
+
+    def slab_size(self):
+        return self._lib.gsx_vote_slab_size(self.h)
+
+    def vote_slab_reduce(self, recv_counts_ptr, recv_first_ptr):
+        check(self._lib.gsx_vote_slab_reduce(self.h, C.c_void_p(recv_counts_ptr), C.c_void_p(recv_first_ptr)), self.h)
+
+    def vote_labels_from_sorted(self, sorted_ptr, to_host=True):
+        out = np.empty(self.n, np.int32) if to_host else None
+        check(self._lib.gsx_vote_labels_from_sorted(self.h, C.c_void_p(sorted_ptr), out.ctypes.data if to_host else None),
+              self.h)
+        return out
+
     def debug_planes(self, bins):
         cnt = np.empty((bins, self.n), np.uint16)
         fv = np.empty((bins, self.n), np.uint16)

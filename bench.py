@@ -45,6 +45,8 @@ def parse():
                     help="experiment: pre-sort the Gaussians on the host before upload")
     ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
     ap.add_argument("--render-splats", type=int, default=3_000_000)
+    ap.add_argument("--exchange", default="a2a", choices=["a2a", "allreduce"],
+                    help="multi-GPU protocol: all-to-all + slab arg-max (v2) or all-reduce of the histogram (v1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + several ranks on one GPU is a functional rehearsal only")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
@@ -135,6 +137,9 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
+    use_a2a = world > 1 and args.exchange == "a2a" and V <= 255
+    if use_a2a:
+        pkg.dist.configure_a2a(ctx, world)
     ctx.upload_positions(pos)
     ctx.vote_begin(args.classes, first, total_views)
     host_segs = []
@@ -147,12 +152,14 @@ def main():
     ctx.synchronize()
     setup_s = time.time() - t0
 
-    shard = pkg.dist.GpuVoteShard(ctx)
+    shard = pkg.dist.GpuSlabShard(ctx) if use_a2a else pkg.dist.GpuVoteShard(ctx)
 
     def step():
         ctx.vote_rewind()
         if world == 1:
             ctx.vote_finalize(to_host=False)      # fused kernel -> int32 labels in HBM
+        elif use_a2a:
+            pkg.dist.exchange_labels_a2a(shard, to_host=False)
         else:
             pkg.dist.exchange_labels(shard, to_host=False)
 
@@ -200,7 +207,7 @@ def main():
                 # positions once (12 B) + one u8 seg gather per visible pair + int32 label
                 alg = 12.0 * n + 1.0 * n_vis + 4.0 * n + 192.0 * V
             else:
-                esz = 2 if total_views > 255 else 1
+                esz = 1 if (use_a2a or total_views <= 255) else 2
                 alg = 12.0 * n + 1.0 * n_vis + 2.0 * esz * (args.classes + 1) * n + 192.0 * V
             achieved = alg / (k_ms * 1e-3) / 1e9
             traffic = None
@@ -249,6 +256,8 @@ def main():
                                    f"BASELINE configs[{2 if world == 1 else 3}]",
                        "gaussians": n, "views_per_gpu": V, "views_total": total_views, "width": W, "height": H,
                        "classes": args.classes, "parallelism": f"views sharded x{world}",
+                       "exchange": None if world == 1 else ("all_to_all + slab arg-max + all_gather(labels)" if use_a2a else
+                                                            "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"),
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
                        "setup_seconds": round(setup_s, 1)},

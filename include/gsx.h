@@ -73,6 +73,7 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 1, 2, 4, 8
  *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
  *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
+ *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the
  *                               views staged after the call) */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
@@ -142,6 +143,21 @@ void* gsx_vote_counts_device(gsx_ctx* ctx, int64_t* n_int32_words);
 int gsx_vote_tiebreak_keys(gsx_ctx* ctx);
 void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words);
 int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out);
+/* ---- multi-GPU exchange, protocol v2: all-to-all instead of all-reduce (SURVEY.md section 5's preferred shape)
+ * Set the options "exchange_slabs" = world size and "exchange_local" = 1 BEFORE gsx_vote_begin: the planes
+ * become u8 [slab][bins][sn] with per-rank counters (<= 255 views per rank) and LOCAL first-view codes.
+ *   rank-local:  gsx_vote_flush
+ *   exchange 1:  all_to_all (equal splits) over gsx_vote_counts_device() and over gsx_vote_first_device():
+ *                rank j receives slab j of every rank, [src rank][bins][sn]           -- 2 x bins*n/world bytes/peer
+ *   rank-local:  gsx_vote_slab_reduce(recv_counts, recv_first): sums the counters and resolves ties by
+ *                (lowest rank, earliest local view) = globally earliest view, since ranks own contiguous
+ *                rank-ordered view blocks -> sn int32 labels of this rank's slab at gsx_vote_keys_device()
+ *   exchange 2:  all_gather of the slab labels -> slabs*sn int32 in Morton (upload) order
+ *   rank-local:  gsx_vote_labels_from_sorted(all_labels_dev, labels_out): back to the caller's order */
+void* gsx_vote_first_device(gsx_ctx* ctx, int64_t* n_int32_words);
+int64_t gsx_vote_slab_size(const gsx_ctx* ctx);
+int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev);
+int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out);
 /* copies of the rank-local planes for tests: counts[bins][n] and first-view codes, widened to u16 */
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out);
 

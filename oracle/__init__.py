@@ -319,3 +319,42 @@ def hit_test(buffer, labels, cam, W, H, x, y):
     label = f(len(buffer), buffer.ctypes.data, _ptr(lab), view.ctypes.data, proj.ctypes.data, float(x), float(y), float(W),
               float(H), C.addressof(idx))
     return int(label), int(idx.value)
+
+
+class NumpySlabShard:
+    """CPU stand-in for one rank of exchange protocol v2 (dist.exchange_labels_a2a), gloo tests only.
+    Planes are u8 [slab][bins][sn]: per-rank counters and LOCAL first-view codes (255 - local index)."""
+
+    def __init__(self, positions, cams, segs, img_sizes, n_classes, world):
+        assert len(cams) <= 255
+        self.n = len(positions)
+        self.bins = n_classes + 1
+        self.world = world
+        self.sn = ((self.n + world - 1) // world + 255) // 256 * 256
+        cnt = np.zeros((self.bins, world * self.sn), np.uint8)
+        fv = np.zeros((self.bins, world * self.sn), np.uint8)
+        idx = np.arange(self.n)
+        for k, (cam, seg, sz) in enumerate(zip(cams, segs, img_sizes)):
+            b = view_bins(positions, cam, seg, sz)
+            m = b >= 0
+            cnt[b[m], idx[m]] += 1
+            fv[b[m], idx[m]] = np.maximum(fv[b[m], idx[m]], 255 - k)
+        # [bins][world*sn] -> [slab][bins][sn]
+        self.cnt = np.ascontiguousarray(cnt.reshape(self.bins, world, self.sn).transpose(1, 0, 2))
+        self.fv = np.ascontiguousarray(fv.reshape(self.bins, world, self.sn).transpose(1, 0, 2))
+
+    def reduce(self, recv_cnt, recv_fv):
+        S, bins, sn = self.world, self.bins, self.sn
+        rc = recv_cnt.reshape(S, bins, sn).astype(np.int64)
+        rf = recv_fv.reshape(S, bins, sn).astype(np.int64)
+        total = rc.sum(0)
+        first_r = np.argmax(rc > 0, axis=0)                                    # lowest rank that voted the bin
+        code = np.take_along_axis(rf, first_r[None], 0)[0]
+        key = np.where(total > 0, ((S - first_r) << 8) | code, 0)
+        M = total.max(0)
+        cand = (total == M[None]) & (total > 0)
+        best = np.where(cand, key, -1).argmax(0)
+        return np.where(M > 0, best - 1, -1).astype(np.int32)
+
+    def finish(self, all_labels):
+        return np.asarray(all_labels[:self.n], dtype=np.int32)

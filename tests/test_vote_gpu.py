@@ -203,6 +203,46 @@ def test_view_sharding_exchange_on_one_gpu(gsx, ctx):
             assert np.array_equal(c.vote_labels_from_keys(), want)
 
 
+def test_all_to_all_exchange_on_one_gpu(gsx):
+    """Exchange protocol v2 with three contexts playing three ranks; the all-to-all and the all-gather are
+    done by hand with torch slices.  Also checks the slab-major u8 planes against the numpy stand-in."""
+    import torch
+    n, V, world = 50_001, 11, 3
+    pos, cams, segs = scene.make_scene(n, V, 320, 180, n_classes=9, config_id=31, convention="w2c")
+    sizes = [(320, 180)] * V
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    for spatial in (0, 1):
+        ctxs, cnts, fvs = [], [], []
+        try:
+            for r in range(world):
+                c = gsx.Context(0)
+                ctxs.append(c)
+                c.set_option("spatial_sort", spatial)
+                gsx.dist.configure_a2a(c, world)
+                lo, hi = gsx.dist.view_range(V, r, world)
+                run_gpu(c, pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], n_classes=9, first=lo, total=V)
+                cnt, fv = gsx.dist.GpuSlabShard(c).planes()
+                cnts.append(cnt)
+                fvs.append(fv)
+                if spatial == 0:
+                    sh = oracle.NumpySlabShard(pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], 9, world)
+                    assert c.slab_size() == sh.sn
+                    assert np.array_equal(cnt.cpu().numpy().view(np.uint8), sh.cnt.reshape(-1))
+                    assert np.array_equal(fv.cpu().numpy().view(np.uint8), sh.fv.reshape(-1))
+            chunk = cnts[0].numel() // world
+            slabs = []
+            for r in range(world):
+                rc = torch.cat([cnts[s][r * chunk:(r + 1) * chunk] for s in range(world)])     # == all_to_all_single
+                rf = torch.cat([fvs[s][r * chunk:(r + 1) * chunk] for s in range(world)])
+                slabs.append(gsx.dist.GpuSlabShard(ctxs[r]).reduce(rc, rf).clone())
+            full = torch.cat(slabs)                                                             # == all_gather
+            for r in range(world):
+                assert np.array_equal(gsx.dist.GpuSlabShard(ctxs[r]).finish(full), want), (spatial, r)
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_seg_dtypes_and_device_maps(ctx):
     import torch
     n = 10_000
