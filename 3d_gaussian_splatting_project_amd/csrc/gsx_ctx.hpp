@@ -65,16 +65,19 @@ struct DevBuf {
 
 // ---- per-view descriptor read by the kernels through scalar (wave-uniform) loads ------------------
 struct alignas(16) ViewDesc {
+    // ---- hot part: loaded in ONE batch of scalar loads per view (vote.hip load_view) ----
     double R[9];       // cameras.json rotation, row-major                         (dls.py:60)
     double t[3];       // (-R) @ p in the dgemv association of the oracle           (dls.py:66)
     double fx, fy;     //                                                           (dls.py:54-55)
     double half_w, half_h;  // width/2, height/2                                    (dls.py:76-77)
     double width, height;   // bounds of the visibility test                        (dls.py:80)
-    double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
     long long seg_off;      // byte offset of this view's u8 map in the seg pool
-    int seg_w, seg_h;
+    int seg_w;
     int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
     int seg_tw;      // 16x8 tiles per map row (0: row-major map)
+    // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
+    int seg_h;
+    double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
 };
 
 struct ProfEvent {

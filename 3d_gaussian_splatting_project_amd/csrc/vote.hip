@@ -36,8 +36,40 @@ static constexpr int kMaxBatch = 255;  // views per fused launch: LDS counters a
 // -------------------------------------------------------------------------------------------------
 // device: project_gaussian + seg-map addressing
 // -------------------------------------------------------------------------------------------------
+// One view's hot fields, held in SGPRs.  load_view() pins all of them behind ONE batch of scalar loads: left
+// to itself hipcc sinks every s_load next to its first use, behind the early-out branches, and each view
+// then pays ~5 exposed scalar-cache round trips (the kernel was waiting, not computing).
+struct ViewRegs {
+    double R[9], t[3], fx, fy, half_w, half_h, width, height;
+    long long seg_off;
+    int seg_w, unit_scale, seg_tw;
+};
+
+__device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
+    ViewRegs r;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.R[k] = vp->R[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.t[k] = vp->t[k];
+    r.fx = vp->fx;
+    r.fy = vp->fy;
+    r.half_w = vp->half_w;
+    r.half_h = vp->half_h;
+    r.width = vp->width;
+    r.height = vp->height;
+    r.seg_off = vp->seg_off;
+    r.seg_w = vp->seg_w;
+    r.unit_scale = vp->unit_scale;
+    r.seg_tw = vp->seg_tw;
+    asm volatile("" : "+s"(r.R[0]), "+s"(r.R[1]), "+s"(r.R[2]), "+s"(r.R[3]), "+s"(r.R[4]), "+s"(r.R[5]), "+s"(r.R[6]),
+                      "+s"(r.R[7]), "+s"(r.R[8]), "+s"(r.t[0]), "+s"(r.t[1]), "+s"(r.t[2]), "+s"(r.fx), "+s"(r.fy),
+                      "+s"(r.half_w), "+s"(r.half_h), "+s"(r.width), "+s"(r.height), "+s"(r.seg_off), "+s"(r.seg_w),
+                      "+s"(r.unit_scale), "+s"(r.seg_tw));
+    return r;
+}
+
 // OpenBLAS dgemv association of `R @ v` for a C-contiguous 3x3 (oracle/vote_oracle.c, header)
-__device__ __forceinline__ double row_dot(const double* __restrict__ Rr, double v0, double v1, double v2) {
+__device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1, double v2) {
     return __builtin_fma(Rr[2], v2, __builtin_fma(Rr[0], v0, Rr[1] * v1));
 }
 
@@ -66,7 +98,7 @@ __device__ __forceinline__ void div2_shared(double ax, double ay, double b, doub
 
 // returns false where the reference returns None (dls.py:72-73, 80-82)
 template <bool SHARED_RCP>
-__device__ __forceinline__ bool project(const ViewDesc& vd, double X, double Y, double Z, int& xi, int& yi) {
+__device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
     if (!(pc2 > 0.0)) return false;  // `pc2 <= 0` -> None; a NaN depth fails the bounds test below anyway
     const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
@@ -88,14 +120,16 @@ __device__ __forceinline__ bool project(const ViewDesc& vd, double X, double Y, 
 
 // byte offset of the voted pixel inside the seg pool, or -1 (dls.py:276-288)
 template <bool SHARED_RCP>
-__device__ __forceinline__ long long seg_index(const ViewDesc& vd, double X, double Y, double Z) {
+__device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, double X, double Y, double Z) {
+    const ViewRegs vd = load_view(vp);
     int xi, yi;
     if (!project<SHARED_RCP>(vd, X, Y, Z, xi, yi)) return -1;
     if (!vd.unit_scale) {
-        const double xs = trunc((double)xi * vd.wscale);  // :281
-        const double ys = trunc((double)yi * vd.hscale);  // :282
+        const double xs = trunc((double)xi * vp->wscale);  // :281
+        const double ys = trunc((double)yi * vp->hscale);  // :282
+        const int seg_h = vp->seg_h;
         xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
-        yi = ys > (double)(vd.seg_h - 1) ? vd.seg_h - 1 : (int)ys;  // :286
+        yi = ys > (double)(seg_h - 1) ? seg_h - 1 : (int)ys;        // :286
     }
     if (vd.seg_tw)  // 16x8-pixel tiles of 128 B: a compact patch of pixels is a compact set of cache lines
         return vd.seg_off + (((long long)(yi >> 3) * vd.seg_tw + (xi >> 4)) << 7) + ((yi & 7) << 4) + (xi & 15);
@@ -111,7 +145,8 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int xi, yi;
-    const bool vis = project<SHARED_RCP>(*vd, (double)x[i], (double)y[i], (double)z[i], xi, yi);
+    const ViewRegs vr = load_view(vd);
+    const bool vis = project<SHARED_RCP>(vr, (double)x[i], (double)y[i], (double)z[i], xi, yi);
     const long long o = perm ? (long long)perm[i] : i;  // back to the caller's order
     ox[o] = vis ? xi : -1;
     oy[o] = vis ? yi : -1;
@@ -178,7 +213,8 @@ struct FusedParams {
 };
 
 template <int U, bool SHARED_RCP>
-__global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, int* __restrict__ labels) {
+__global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                   int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
     uint32_t* row = lds + threadIdx.x * p.stride_dw;
     for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
@@ -201,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {  // wave-uniform
-                const long long off = seg_index<SHARED_RCP>(p.views[v], X, Y, Z);
+                const long long off = seg_index<SHARED_RCP>(views + v, X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -237,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 // fv code = FVMAX - global view index of the first vote (larger = earlier; 0 = no vote).
 // -------------------------------------------------------------------------------------------------
 template <int U, typename PT, bool SHARED_RCP>
-__global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, PT* __restrict__ cnt,
+__global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                   PT* __restrict__ cnt,
                                                                    PT* __restrict__ fv, long long sn,
                                                                    int view_base, int fresh, int local_codes) {
     constexpr int FVMAX = sizeof(PT) == 1 ? 255 : 65535;
@@ -260,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {
-                const long long off = seg_index<SHARED_RCP>(p.views[v], X, Y, Z);
+                const long long off = seg_index<SHARED_RCP>(views + v, X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -637,12 +674,12 @@ int vote_flush(Ctx* c) {
         if (c->wide) {
             auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint16_t, true> : vote_fused_planes_kernel<kUnroll, uint16_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint16_t>(),
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint16_t>(),
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
             auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint8_t, true> : vote_fused_planes_kernel<kUnroll, uint8_t, false>;
             if ((rc = set_lds(c, k, lds))) return rc;
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->cnt.as<uint8_t>(),
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
                                c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
         }
         GSX_HIP(c, hipGetLastError());
@@ -726,7 +763,7 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
                                                : (sr ? vote_fused_labels_kernel<8, true> : vote_fused_labels_kernel<8, false>);
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, c->labels.as<int>());
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());
             GSX_HIP(c, hipGetLastError());
         }
         return labels_to_host(c, labels_out);
