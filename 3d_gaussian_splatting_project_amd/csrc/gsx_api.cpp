@@ -149,9 +149,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         c->opt_slabs = (int)value;
     } else if (k == "exchange_local") c->opt_local_codes = value != 0;
     else if (k == "shared_rcp") c->opt_shared_rcp = value != 0;
+    else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "vote_unroll") {
-        if (value != 1 && value != 2 && value != 4 && value != 8)
-            return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 1, 2, 4 or 8");
+        if (value != 2 && value != 4 && value != 8)
+            return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 2, 4 or 8");
         c->opt_vote_unroll = (int)value;
     } else
         return gsx::fail(c, GSX_E_INVALID, "set_option: unknown option '%s'", name);

@@ -212,7 +212,7 @@ struct FusedParams {
     const uint32_t* perm;  // sorted slot -> caller's index, or nullptr
 };
 
-template <int U, bool SHARED_RCP>
+template <int U, bool SHARED_RCP, bool LDS_BATCH>
 __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
@@ -241,21 +241,35 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
                 if (off >= 0) bin[u] = pool[off];
             }
         }
-        // one LDS round trip for the whole chunk: read the U counters first, resolve repeats of a bin
-        // inside the chunk in registers, then apply the votes in (reverse view) order
-        int old[U];
+        if (LDS_BATCH) {
+            // one LDS round trip for the whole chunk: read the U counters first, resolve repeats of a bin
+            // inside the chunk in registers, then apply the votes in (reverse view) order
+            int old[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (int)h[bin[u]] : 0;
+            for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (int)h[bin[u]] : 0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (bin[u] >= 0) {
-                int c = old[u] + 1;  // dls.py:295
+            for (int u = 0; u < U; ++u) {
+                if (bin[u] >= 0) {
+                    int c = old[u] + 1;  // dls.py:295
 #pragma unroll
-                for (int w = 0; w < u; ++w) c += (bin[w] == bin[u]) ? 1 : 0;
-                h[bin[u]] = (uint8_t)c;  // LDS stores of one wave retire in order: the last repeat wins
-                if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
-                    bestc = c;
-                    best = bin[u];
+                    for (int w = 0; w < u; ++w) c += (bin[w] == bin[u]) ? 1 : 0;
+                    h[bin[u]] = (uint8_t)c;  // LDS stores of one wave retire in order: the last repeat wins
+                    if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
+                        bestc = c;
+                        best = bin[u];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (bin[u] >= 0) {
+                    const int c = h[bin[u]] + 1;  // dls.py:295
+                    h[bin[u]] = (uint8_t)c;
+                    if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
+                        bestc = c;
+                        best = bin[u];
+                    }
                 }
             }
         }
@@ -756,11 +770,17 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
             p.stride_dw = odd_dwords(c->bins);
             const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-            const bool sr = c->opt_shared_rcp != 0;
-            auto k = c->opt_vote_unroll == 1   ? (sr ? vote_fused_labels_kernel<1, true> : vote_fused_labels_kernel<1, false>)
-                     : c->opt_vote_unroll == 2 ? (sr ? vote_fused_labels_kernel<2, true> : vote_fused_labels_kernel<2, false>)
-                     : c->opt_vote_unroll == 4 ? (sr ? vote_fused_labels_kernel<4, true> : vote_fused_labels_kernel<4, false>)
-                                               : (sr ? vote_fused_labels_kernel<8, true> : vote_fused_labels_kernel<8, false>);
+            // kernel variants: unroll U in {2,4,8} x shared reciprocal x batched LDS reads
+            using K = void (*)(FusedParams, const ViewDesc*, int*);
+            const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
+            static const K table[3][2][2] = {
+                {{vote_fused_labels_kernel<2, false, false>, vote_fused_labels_kernel<2, false, true>},
+                 {vote_fused_labels_kernel<2, true, false>, vote_fused_labels_kernel<2, true, true>}},
+                {{vote_fused_labels_kernel<4, false, false>, vote_fused_labels_kernel<4, false, true>},
+                 {vote_fused_labels_kernel<4, true, false>, vote_fused_labels_kernel<4, true, true>}},
+                {{vote_fused_labels_kernel<8, false, false>, vote_fused_labels_kernel<8, false, true>},
+                 {vote_fused_labels_kernel<8, true, false>, vote_fused_labels_kernel<8, true, true>}}};
+            K k = table[ui][c->opt_shared_rcp ? 1 : 0][c->opt_lds_batch ? 1 : 0];
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());

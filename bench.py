@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--render-splats", type=int, default=3_000_000)
     ap.add_argument("--exchange", default="a2a", choices=["a2a", "allreduce"],
                     help="multi-GPU protocol: all-to-all + slab arg-max (v2) or all-reduce of the histogram (v1)")
+    ap.add_argument("--force-exchange-path", action="store_true",
+                    help="N=1 only: run the multi-GPU code path (planes kernel + slab reduce) on one GPU to time its kernels")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + several ranks on one GPU is a functional rehearsal only")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
@@ -137,7 +139,7 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    use_a2a = world > 1 and args.exchange == "a2a" and V <= 255
+    use_a2a = (world > 1 or args.force_exchange_path) and args.exchange == "a2a" and V <= 255
     if use_a2a:
         pkg.dist.configure_a2a(ctx, world)
     ctx.upload_positions(pos)
@@ -156,7 +158,7 @@ def main():
 
     def step():
         ctx.vote_rewind()
-        if world == 1:
+        if world == 1 and not args.force_exchange_path:
             ctx.vote_finalize(to_host=False)      # fused kernel -> int32 labels in HBM
         elif use_a2a:
             pkg.dist.exchange_labels_a2a(shard, to_host=False)
@@ -188,7 +190,7 @@ def main():
     value = n * total_views / (elapsed / args.steps)
 
     # ---- dominant kernel: HIP-event time on the ctx stream, algorithmic bytes / time ------------------
-    kname = "vote_fused_labels" if world == 1 else "vote_fused_planes"
+    kname = "vote_fused_labels" if (world == 1 and not args.force_exchange_path) else "vote_fused_planes"
     roofline = None
     vis_frac = None
     if rank == 0:
@@ -203,7 +205,7 @@ def main():
         if launches:
             k_ms = total_ms / launches
             n_vis = vis_frac * n * V
-            if world == 1:
+            if kname == "vote_fused_labels":
                 # positions once (12 B) + one u8 seg gather per visible pair + int32 label
                 alg = 12.0 * n + 1.0 * n_vis + 4.0 * n + 192.0 * V
             else:

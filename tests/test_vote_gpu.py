@@ -73,7 +73,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     pos, cams, segs = scene.make_scene(n, 9, 480, 270, config_id=12, convention="w2c")
     sizes = [(480, 270)] * 9
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
-    for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 1, "seg_tiled": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
+    for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "shared_rcp": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
