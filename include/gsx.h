@@ -71,7 +71,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 2, 4, 8
- *   "lds_batch"    (default 1)  read the LDS counters of a whole chunk of views in one round trip
+ *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
+ *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
  *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
  *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
