@@ -329,12 +329,39 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
             }
         }
     }
-    if (!valid) return;
     // planes are slab-major: [slab][bin][sn] with slab = i / sn (one slab = one rank's share in the
-    // all-to-all exchange; a single slab is the plain [bin][n_pad] layout)
+    // all-to-all exchange; a single slab is the plain [bin][n_pad] layout).  sn is a multiple of the block
+    // size, so a workgroup never straddles two slabs.
+    const int vb0 = local_codes ? 0 : view_base;  // local codes: 255 - index inside this rank's batch
+    if (sizeof(PT) == 1 && fresh) {
+        // Transposed store through the wave's own LDS rows: lane (g, t) = (lane / 16, lane % 16) packs bin
+        // 4*it + g of Gaussians 4t .. 4t+3 into one dword per plane, so a wave writes 4 bins x 64 B per
+        // instruction pair instead of 1 bin x 64 single bytes.  Rows of lanes past n hold zeros.
+        const int lane = threadIdx.x & 63;
+        const int g = lane >> 4, t = lane & 15;
+        const long long i0 = i - lane;  // first Gaussian of this wave
+        const long long slab = i0 / sn;
+        const long long base = slab * p.bins * sn + (i0 - slab * sn) + 4 * t;
+        const uint32_t* wrow = lds + (threadIdx.x - lane + 4 * t) * p.stride_dw;
+        for (int b = g; b < p.bins; b += 4) {
+            uint32_t pc = 0, pf = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned w = reinterpret_cast<const uint16_t*>(wrow + k * p.stride_dw)[b];
+                const unsigned c = w >> 8;
+                const unsigned code = c ? (unsigned)(FVMAX - (vb0 + (int)(w & 0xffu))) : 0u;
+                pc |= c << (8 * k);
+                pf |= code << (8 * k);
+            }
+            const long long at = base + (long long)b * sn;
+            *reinterpret_cast<uint32_t*>(cnt + at) = pc;
+            *reinterpret_cast<uint32_t*>(fv + at) = pf;
+        }
+        return;
+    }
+    if (!valid) return;
     const long long slab = i / sn;
     const long long base = slab * p.bins * sn + (i - slab * sn);
-    const int vb0 = local_codes ? 0 : view_base;  // local codes: 255 - index inside this rank's batch
     for (int b = 0; b < p.bins; ++b) {
         const unsigned w = h[b];
         const unsigned c = w >> 8;
