@@ -22,7 +22,14 @@
 #include <thread>
 #include <vector>
 
-#include "gsx_ctx.hpp"
+#include "../../include/gsx.h"
+
+// error plumbing of libgsx (gsx_api.cpp); declared here so that this file needs no HIP header and can be
+// built host-only (tests/test_ply_asan.py runs it under AddressSanitizer)
+namespace gsx {
+struct Ctx;
+int fail(Ctx* c, int code, const char* fmt, ...);
+}  // namespace gsx
 
 namespace {
 

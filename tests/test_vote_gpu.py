@@ -326,3 +326,38 @@ def test_full_size_properties(ctx):
     want = oracle.assign_labels(np.ascontiguousarray(pos[sample]), cams, segs, [(W, H)] * V, threads=0)
     assert np.array_equal(a[sample], want)
     assert (a != -1).mean() > 0.9 and len(np.unique(a)) == 151
+
+
+def test_randomised_small_configurations(gsx):
+    """Many small random configurations (sizes, class counts, scales, map dtypes, camera frames that do not
+    match the map, missing visibility, options) against the oracle — bit-exact every time."""
+    rng = np.random.default_rng(2024)
+    with gsx.Context(0) as c:
+        for trial in range(40):
+            n = int(rng.integers(1, 3000))
+            V = int(rng.integers(1, 12))
+            C = int(rng.choice([1, 2, 7, 80, 150, 255]))
+            c.set_option("spatial_sort", int(rng.integers(0, 2)))
+            c.set_option("seg_tiled", int(rng.integers(0, 2)))
+            c.set_option("vote_unroll", int(rng.choice([2, 4, 8])))
+            c.set_option("lds_batch", int(rng.integers(0, 2)))
+            pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
+            cams, segs, sizes = [], [], []
+            for v in range(V):
+                W, H = int(rng.integers(8, 200)), int(rng.integers(8, 150))
+                cam = scene.make_cameras(V + 3, W, H, radius=float(rng.uniform(3, 9)), convention=str(rng.choice(["w2c", "c2w"])))[v]
+                cam["fx"] = float(rng.uniform(0.3, 2.0) * W)
+                cam["fy"] = float(rng.uniform(0.3, 2.0) * W)
+                sw, sh = (W, H) if rng.random() < 0.5 else (int(rng.integers(1, 260)), int(rng.integers(1, 200)))
+                iw, ih = (W, H) if rng.random() < 0.6 else (int(rng.integers(4, 300)), int(rng.integers(4, 300)))
+                seg = rng.integers(-1, C, size=(sh, sw)).astype(rng.choice([np.int32, np.int64]))
+                cams.append(cam)
+                segs.append(seg)
+                sizes.append((iw, ih))
+            want = oracle.assign_labels(pos, cams, segs, sizes, threads=1)
+            got = run_gpu(c, pos, cams, segs, sizes, n_classes=C).vote_finalize()
+            assert np.array_equal(got, want), (trial, n, V, C)
+            c.vote_rewind()
+            c.vote_flush()
+            c.vote_tiebreak_keys()
+            assert np.array_equal(c.vote_labels_from_keys(), want), (trial, "planes")
