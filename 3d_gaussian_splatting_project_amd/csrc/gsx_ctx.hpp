@@ -126,6 +126,7 @@ struct Ctx {
     int n_flushed = 0;         // views [0, n_flushed) are already in the planes
     bool planes_valid = false;  // planes hold votes (zeroed at begin/rewind)
     bool planes_zero = false;   // planes are known to be all-zero
+    bool planes_stale = false;  // planes hold a rewound run's votes; the next fresh flush overwrites them
     DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
     DevBuf keys, labels;        // [n_pad] int32
     bool labels_valid = false;

@@ -534,6 +534,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->n_flushed = 0;
     c->planes_valid = false;
     c->planes_zero = false;
+    c->planes_stale = false;
     c->labels_valid = false;
     GSX_HIP(c, c->errflag.ensure(sizeof(int)));
     GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
@@ -647,12 +648,26 @@ static int ensure_planes(Ctx* c) {
     const bool grew = bytes > c->cnt.cap || bytes > c->fv.cap;
     GSX_HIP(c, c->cnt.ensure(bytes ? bytes : 4));
     GSX_HIP(c, c->fv.ensure(bytes ? bytes : 4));
-    if (grew || !(c->planes_valid || c->planes_zero)) {
+    if (grew || !(c->planes_valid || c->planes_zero || c->planes_stale)) {
         GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));
         GSX_HIP(c, hipMemsetAsync(c->fv.p, 0, bytes, c->stream));
         c->planes_zero = true;
         c->planes_valid = false;
+        c->planes_stale = false;
     }
+    return GSX_OK;
+}
+
+// After a rewind the planes still hold the previous run's votes ("stale"): the next flush overwrites every
+// element of every Gaussian with its first batch, so nothing is cleared up front (2 x 453 MB of memset per
+// step at C3).  Anything that reads the planes before such a flush clears them here.
+static int clear_stale_planes(Ctx* c) {
+    if (!c->planes_stale) return GSX_OK;
+    const size_t bytes = (size_t)c->bins * (size_t)c->n_pad * (c->wide ? 2 : 1);
+    GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));
+    GSX_HIP(c, hipMemsetAsync(c->fv.p, 0, bytes, c->stream));
+    c->planes_stale = false;
+    c->planes_zero = true;
     return GSX_OK;
 }
 
@@ -662,11 +677,9 @@ int vote_rewind(Ctx* c) {
     c->n_flushed = 0;
     c->labels_valid = false;
     if (c->planes_valid) {
-        const size_t bytes = (size_t)c->bins * (size_t)c->n_pad * (c->wide ? 2 : 1);
-        GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));
-        GSX_HIP(c, hipMemsetAsync(c->fv.p, 0, bytes, c->stream));
         c->planes_valid = false;
-        c->planes_zero = true;
+        c->planes_zero = false;
+        c->planes_stale = true;  // cleared lazily, see clear_stale_planes
     }
     return GSX_OK;
 }
@@ -690,9 +703,9 @@ int vote_flush(Ctx* c) {
     rc = ensure_planes(c);
     if (rc) return rc;
     const int nv = (int)c->views.size();
-    if (c->n <= 0) {
+    if (c->n <= 0 || c->n_flushed >= nv) {
         c->n_flushed = nv;
-        return GSX_OK;
+        return clear_stale_planes(c);  // nothing will overwrite them
     }
     FusedParams p{};
     p.x = c->x.as<float>();
@@ -710,7 +723,7 @@ int vote_flush(Ctx* c) {
         p.views = c->d_views.as<ViewDesc>() + c->n_flushed;
         p.nviews = batch;
         const int view_base = c->first_view + c->n_flushed;
-        const int fresh = c->planes_zero ? 1 : 0;
+        const int fresh = (c->planes_zero || c->planes_stale) ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
             auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint16_t, true> : vote_fused_planes_kernel<kUnroll, uint16_t, false>;
@@ -725,6 +738,7 @@ int vote_flush(Ctx* c) {
         }
         GSX_HIP(c, hipGetLastError());
         c->planes_zero = false;
+        c->planes_stale = false;
         c->planes_valid = true;
         c->n_flushed += batch;
     }
@@ -736,6 +750,7 @@ int vote_tiebreak_keys(Ctx* c) {
     GSX_HIP(c, hipSetDevice(c->device));
     int rc = ensure_planes(c);
     if (rc) return rc;
+    if ((rc = clear_stale_planes(c))) return rc;
     GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
     GSX_HIP(c, hipMemsetAsync(c->keys.p, 0, sizeof(int) * (size_t)c->n_pad, c->stream));
     if (c->n <= 0) return GSX_OK;
@@ -850,7 +865,11 @@ int vote_labels_from_sorted(Ctx* c, const void* sorted_labels_dev, int32_t* labe
 }
 
 int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out) {
-    if (!c->vote_begun || !(c->planes_valid || c->planes_zero)) return fail(c, GSX_E_STATE, "vote_debug_planes: no planes");
+    if (!c->vote_begun || !(c->planes_valid || c->planes_zero || c->planes_stale)) return fail(c, GSX_E_STATE, "vote_debug_planes: no planes");
+    {
+        const int rc0 = clear_stale_planes(c);
+        if (rc0) return rc0;
+    }
     if (!counts_out || !first_out) return fail(c, GSX_E_INVALID, "vote_debug_planes: NULL argument");
     GSX_HIP(c, hipSetDevice(c->device));
     const size_t esz = c->wide ? 2 : 1;

@@ -250,7 +250,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "Gaussian-views/sec labelled (3M Gaussians, 1080p views, majority vote)",
+            "metric": "Gaussians·views/sec labelled (3M G, 1080p), majority vote",
             "value": round(value, 1), "unit": "Gaussian·views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
