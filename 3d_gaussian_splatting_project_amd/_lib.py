@@ -72,6 +72,12 @@ _SIGS = {
     "gsx_vote_first_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gsx_vote_slab_size": (C.c_int64, [C.c_void_p]),
     "gsx_vote_slab_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsx_vote_flush_counts": (C.c_int, [C.c_void_p]),
+    "gsx_vote_slab_totals": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gsx_vote_cand_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gsx_vote_tie_codes": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gsx_vote_codes_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
+    "gsx_vote_tie_resolve": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_vote_labels_from_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_upload_splats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6),

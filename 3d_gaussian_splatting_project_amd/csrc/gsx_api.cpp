@@ -119,7 +119,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
-                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
+                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();
@@ -309,6 +309,34 @@ int64_t gsx_vote_slab_size(const gsx_ctx* ctx) {
 int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev) {
     CTX_OR_FAIL(ctx);
     return gsx::vote_slab_reduce(c, recv_counts_dev, recv_first_dev);
+}
+int gsx_vote_flush_counts(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_flush_counts(c);
+}
+int gsx_vote_slab_totals(gsx_ctx* ctx, const void* recv_counts_dev) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_slab_totals(c, recv_counts_dev);
+}
+void* gsx_vote_cand_device(gsx_ctx* ctx, int64_t* n_int32_words) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !c->vote_begun) return nullptr;
+    if (n_int32_words) *n_int32_words = 8 * c->sn;
+    return c->cand.p;
+}
+int gsx_vote_tie_codes(gsx_ctx* ctx, const void* cand_all_dev) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_tie_codes(c, cand_all_dev);
+}
+void* gsx_vote_codes_device(gsx_ctx* ctx, int64_t* n_int32_words) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || !c->vote_begun) return nullptr;
+    if (n_int32_words) *n_int32_words = c->n_pad / 2;
+    return c->codes.p;
+}
+int gsx_vote_tie_resolve(gsx_ctx* ctx, const void* recv_codes_dev) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_tie_resolve(c, recv_codes_dev);
 }
 int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);

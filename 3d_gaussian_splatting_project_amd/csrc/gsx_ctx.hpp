@@ -129,6 +129,7 @@ struct Ctx {
     bool planes_stale = false;  // planes hold a rewound run's votes; the next fresh flush overwrites them
     DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
     DevBuf keys, labels;        // [n_pad] int32
+    DevBuf cand, codes;         // exchange v3: candidate masks u32[8][sn] of this slab; tie codes u16[n_pad]
     bool labels_valid = false;
 
     // rasterizer (render.hip / blend.hip)
@@ -176,6 +177,10 @@ int vote_tiebreak_keys(Ctx* c);
 int vote_labels_from_keys(Ctx* c, int32_t* labels_out);
 int vote_debug_planes(Ctx* c, uint16_t* counts_out, uint16_t* first_out);
 int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv);
+int vote_flush_counts(Ctx* c);
+int vote_slab_totals(Ctx* c, const void* recv_cnt);
+int vote_tie_codes(Ctx* c, const void* cand_all);
+int vote_tie_resolve(Ctx* c, const void* recv_codes);
 int vote_labels_from_sorted(Ctx* c, const void* sorted_labels_dev, int32_t* labels_out);
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
                 int32_t* x_host, int32_t* y_host, const uint32_t* perm);

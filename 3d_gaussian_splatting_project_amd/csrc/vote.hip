@@ -281,6 +281,139 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 }
 
 // -------------------------------------------------------------------------------------------------
+// exchange protocol v3, rank-local part 1: the same walk as the labels kernel (u8 counters, 16 waves/CU)
+// but the only output is this rank's COUNT plane, u8 [slab][bins][sn].  No first-view plane: ties are
+// resolved later, for the tied Gaussians only, by vote_tie_kernel.
+// -------------------------------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                   uint8_t* __restrict__ cnt, long long sn) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;
+    uint8_t* h = reinterpret_cast<uint8_t*>(row);
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const double X = valid ? (double)p.x[i] : __builtin_nan("");
+    const double Y = valid ? (double)p.y[i] : 0.0;
+    const double Z = valid ? (double)p.z[i] : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+    for (int vb = p.nviews; vb > 0; vb -= U) {
+        int bin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            bin[u] = -1;
+            if (v >= 0) {
+                const long long off = seg_index<false>(views + v, X, Y, Z);
+                if (off >= 0) bin[u] = pool[off];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (bin[u] >= 0) h[bin[u]] = (uint8_t)(h[bin[u]] + 1);
+    }
+    // transposed store (see vote_fused_planes_kernel): lane (g, t) packs bin 4*it+g of Gaussians 4t..4t+3
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, t = lane & 15;
+    const long long i0 = i - lane;
+    const long long slab = i0 / sn;
+    const long long base = slab * p.bins * sn + (i0 - slab * sn) + 4 * t;
+    const uint32_t* wrow = lds + (threadIdx.x - lane + 4 * t) * p.stride_dw;
+    for (int b = g; b < p.bins; b += 4) {
+        uint32_t pc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pc |= (uint32_t)reinterpret_cast<const uint8_t*>(wrow + k * p.stride_dw)[b] << (8 * k);
+        *reinterpret_cast<uint32_t*>(cnt + base + (long long)b * sn) = pc;
+    }
+}
+
+// v3, slab owner: sum the S ranks' counters per bin; a unique maximum is the label, otherwise the Gaussian is
+// TIED (label -2 for now) and the set of max-count bins goes out as a bit mask, cand[word][sn], 8 words.
+static constexpr int kCandWords = 8;  // bins <= 256
+__global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t* __restrict__ rcnt, int S, int bins,
+                                                                  long long sn, int* __restrict__ slab_labels,
+                                                                  uint32_t* __restrict__ cand) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= sn) return;
+    unsigned M = 0;
+    for (int b = 0; b < bins; ++b) {
+        unsigned total = 0;
+        for (int r = 0; r < S; ++r) total += rcnt[((long long)r * bins + b) * sn + i];
+        M = max(M, total);
+    }
+    int n_max = 0, first_bin = -1;
+    for (int w = 0; w < kCandWords; ++w) {
+        uint32_t word = 0;
+        for (int bb = 0; bb < 32; ++bb) {
+            const int b = w * 32 + bb;
+            if (b >= bins) break;
+            unsigned total = 0;
+            for (int r = 0; r < S; ++r) total += rcnt[((long long)r * bins + b) * sn + i];
+            if (M > 0 && total == M) {
+                word |= 1u << bb;
+                if (n_max == 0) first_bin = b;
+                ++n_max;
+            }
+        }
+        cand[(long long)w * sn + i] = word;
+    }
+    slab_labels[i] = n_max == 0 ? -1 : (n_max == 1 ? first_bin - 1 : -2);
+}
+
+// v3, every rank: for each TIED Gaussian (two or more candidate bins) walk this rank's views in FORWARD order
+// and stop at the first one that votes a candidate: code = (255 - local view index) << 8 | bin, 0 if none.
+// cand_all: [S][kCandWords][sn] (all-gathered masks); codes: u16 [S][sn], slab-major.
+__global__ __launch_bounds__(kBlock) void vote_tie_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                          const uint32_t* __restrict__ cand_all, long long sn,
+                                                          uint16_t* __restrict__ codes) {
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    if (i >= p.n) return;
+    const long long slab = i / sn, j = i - slab * sn;
+    uint32_t mask[kCandWords];
+    int pop = 0;
+#pragma unroll
+    for (int w = 0; w < kCandWords; ++w) {
+        mask[w] = cand_all[(slab * kCandWords + w) * sn + j];
+        pop += __popc(mask[w]);
+    }
+    unsigned code = 0;
+    if (pop >= 2) {
+        const double X = (double)p.x[i], Y = (double)p.y[i], Z = (double)p.z[i];
+        for (int v = 0; v < p.nviews; ++v) {
+            const long long off = seg_index<false>(views + v, X, Y, Z);
+            if (off < 0) continue;
+            const unsigned b = p.pool[off];
+            uint32_t word = 0;
+#pragma unroll
+            for (int w = 0; w < kCandWords; ++w) word = (b >> 5) == (unsigned)w ? mask[w] : word;
+            if ((word >> (b & 31u)) & 1u) {
+                code = ((unsigned)(255 - v) << 8) | b;
+                break;
+            }
+        }
+    }
+    codes[i] = (uint16_t)code;  // == codes[slab][j]: n_pad = S * sn
+}
+
+// v3, slab owner: a tied Gaussian takes the candidate first voted by the LOWEST rank that voted one (ranks own
+// contiguous rank-ordered view blocks), i.e. the globally earliest view.  rcodes: u16 [S(src)][sn].
+__global__ __launch_bounds__(kBlock) void vote_tie_resolve_kernel(const uint16_t* __restrict__ rcodes, int S, long long sn,
+                                                                  int* __restrict__ slab_labels) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= sn || slab_labels[i] != -2) return;
+    int label = -1;
+    for (int r = 0; r < S; ++r) {
+        const unsigned c = rcodes[(long long)r * sn + i];
+        if (c) {
+            label = (int)(c & 0xffu) - 1;
+            break;
+        }
+    }
+    slab_labels[i] = label;
+}
+
+// -------------------------------------------------------------------------------------------------
 // fused vote, planes mode (multi-GPU exchange, or more than kMaxBatch views): the batch's votes
 // are merged into the global planes cnt[bins][n_pad] / fv[bins][n_pad].
 // LDS word per bin: count << 8 | local index of the earliest view that voted it.
@@ -834,6 +967,93 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
     if (rc) return rc;
     if ((rc = vote_tiebreak_keys(c))) return rc;
     return vote_labels_from_keys(c, labels_out);
+}
+
+// ---- exchange v3 host side ------------------------------------------------------------------------------------
+static FusedParams fused_params(Ctx* c, int stride_bytes_per_bin) {
+    FusedParams p{};
+    p.x = c->x.as<float>();
+    p.y = c->y.as<float>();
+    p.z = c->z.as<float>();
+    p.n = c->n;
+    p.views = c->d_views.as<ViewDesc>();
+    p.nviews = (int)c->views.size();
+    p.pool = c->segpool.as<uint8_t>();
+    p.bins = c->bins;
+    p.xcd_swizzle = c->opt_xcd_swizzle;
+    p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
+    p.stride_dw = odd_dwords(c->bins * stride_bytes_per_bin);
+    return p;
+}
+
+int vote_flush_counts(Ctx* c) {
+    if (!c->vote_begun || !c->local_codes) return fail(c, GSX_E_STATE, "vote_flush_counts needs vote_begin with the 'exchange_local' option");
+    GSX_HIP(c, hipSetDevice(c->device));
+    int rc = sync_views(c);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->bins * (size_t)c->n_pad;
+    if (bytes > c->cnt.cap) {
+        GSX_HIP(c, c->cnt.ensure(bytes));
+        GSX_HIP(c, hipMemsetAsync(c->cnt.p, 0, bytes, c->stream));  // pad Gaussians stay zero for ever
+    }
+    if (c->n > 0) {
+        FusedParams p = fused_params(c, 1);
+        const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+        auto k = vote_fused_counts_kernel<kUnroll>;
+        if ((rc = set_lds(c, k, lds))) return rc;
+        ProfScope ps(c, "vote_fused_counts");
+        hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
+                           (long long)c->sn);
+        GSX_HIP(c, hipGetLastError());
+    }
+    c->n_flushed = (int)c->views.size();
+    return GSX_OK;
+}
+
+int vote_slab_totals(Ctx* c, const void* recv_cnt) {
+    if (!c->vote_begun || !c->local_codes) return fail(c, GSX_E_STATE, "vote_slab_totals needs the 'exchange_local' option");
+    if (!recv_cnt) return fail(c, GSX_E_INVALID, "vote_slab_totals: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)c->n_pad));
+    GSX_HIP(c, c->cand.ensure(sizeof(uint32_t) * kCandWords * (size_t)c->sn));
+    ProfScope ps(c, "vote_slab_totals");
+    hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(c->sn)), dim3(kBlock), 0, c->stream, (const uint8_t*)recv_cnt,
+                       c->slabs, c->bins, (long long)c->sn, c->keys.as<int>(), c->cand.as<uint32_t>());
+    GSX_HIP(c, hipGetLastError());
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int vote_tie_codes(Ctx* c, const void* cand_all) {
+    if (!c->vote_begun || !c->local_codes) return fail(c, GSX_E_STATE, "vote_tie_codes needs the 'exchange_local' option");
+    if (!cand_all) return fail(c, GSX_E_INVALID, "vote_tie_codes: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = sizeof(uint16_t) * (size_t)c->n_pad;
+    if (bytes > c->codes.cap) {
+        GSX_HIP(c, c->codes.ensure(bytes));
+        GSX_HIP(c, hipMemsetAsync(c->codes.p, 0, bytes, c->stream));
+    }
+    if (c->n > 0) {
+        FusedParams p = fused_params(c, 1);
+        ProfScope ps(c, "vote_tie");
+        hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, p, p.views,
+                           (const uint32_t*)cand_all, (long long)c->sn, c->codes.as<uint16_t>());
+        GSX_HIP(c, hipGetLastError());
+    }
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int vote_tie_resolve(Ctx* c, const void* recv_codes) {
+    if (!c->vote_begun || !c->local_codes) return fail(c, GSX_E_STATE, "vote_tie_resolve needs the 'exchange_local' option");
+    if (!recv_codes) return fail(c, GSX_E_INVALID, "vote_tie_resolve: NULL argument");
+    GSX_HIP(c, hipSetDevice(c->device));
+    ProfScope ps(c, "vote_tie_resolve");
+    hipLaunchKernelGGL(vote_tie_resolve_kernel, dim3(grid_for(c->sn)), dim3(kBlock), 0, c->stream, (const uint16_t*)recv_codes,
+                       c->slabs, (long long)c->sn, c->keys.as<int>());
+    GSX_HIP(c, hipGetLastError());
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
 }
 
 int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv) {

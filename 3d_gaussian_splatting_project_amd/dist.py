@@ -183,6 +183,100 @@ def exchange_labels_a2a(shard, group=None, to_host=True):
     return shard.finish(full, to_host)
 
 
+# ---- protocol v3: counts-only all-to-all + sparse tie pass ------------------------------------------------------
+#   1. fast u8-histogram kernel -> count plane only, u8 [slab][bins][sn]
+#   2. all_to_all(counts); slab owner: unique max -> label, else TIED + bit mask of the max-count bins
+#   3. all_gather(masks); every rank walks its views forward for the tied Gaussians only, stops at the first
+#      candidate vote -> u16 code (255 - local view) << 8 | bin
+#   4. all_to_all(codes); slab owner: lowest rank with a code = globally earliest view -> label
+#   5. all_gather(labels)
+# Half of v2's bytes on the fabric, and the rank-local kernel is the 16-waves/CU one.
+class GpuSparseShard:
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def _t(self, ptr_words):
+        ptr, words = ptr_words
+        return device_words_tensor(ptr, words, self.ctx.device)
+
+    def counts(self):
+        self.ctx.vote_flush_counts()
+        self.ctx.synchronize()
+        return self._t(self.ctx.counts_device())
+
+    def totals(self, recv_cnt):
+        torch.cuda.synchronize(self.ctx.device)
+        self.ctx.vote_slab_totals(recv_cnt.data_ptr())
+        return self._t(self.ctx.cand_device())
+
+    def tie_codes(self, cand_all):
+        torch.cuda.synchronize(self.ctx.device)
+        self.ctx.vote_tie_codes(cand_all.data_ptr())
+        return self._t(self.ctx.codes_device())
+
+    def resolve(self, recv_codes):
+        torch.cuda.synchronize(self.ctx.device)
+        self.ctx.vote_tie_resolve(recv_codes.data_ptr())
+        kp, _ = self.ctx.keys_device()
+        return device_words_tensor(kp, self.ctx.slab_size(), self.ctx.device)
+
+    def finish(self, all_labels, to_host=True):
+        torch.cuda.synchronize(self.ctx.device)
+        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host)
+
+
+class HostSparseShard:
+    """Adapter for a numpy-backed v3 shard (tests, gloo)."""
+
+    def __init__(self, shard):
+        self.shard = shard
+
+    def counts(self):
+        return torch.from_numpy(self.shard.cnt.reshape(-1).view(np.int32))
+
+    def totals(self, recv_cnt):
+        return torch.from_numpy(self.shard.totals(recv_cnt.numpy().view(np.uint8)).reshape(-1).view(np.int32))
+
+    def tie_codes(self, cand_all):
+        return torch.from_numpy(self.shard.tie_codes(cand_all.numpy().view(np.uint32)).reshape(-1).view(np.int32))
+
+    def resolve(self, recv_codes):
+        return torch.from_numpy(self.shard.resolve(recv_codes.numpy().view(np.uint16)))
+
+    def finish(self, all_labels, to_host=True):
+        return self.shard.finish(all_labels.numpy())
+
+
+def exchange_labels_sparse(shard, group=None, to_host=True):
+    """Protocol v3.  `shard` is a GpuSparseShard (RCCL) or HostSparseShard (gloo)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    cnt = shard.counts()
+    if world > 1:
+        rc = torch.empty_like(cnt)
+        _all_to_all(rc, cnt, group)
+    else:
+        rc = cnt
+    cand = shard.totals(rc)
+    if world > 1:
+        cand_all = torch.empty(cand.numel() * world, dtype=cand.dtype, device=cand.device)
+        _all_gather_into(cand_all, cand, group)
+    else:
+        cand_all = cand
+    codes = shard.tie_codes(cand_all)
+    if world > 1:
+        rcodes = torch.empty_like(codes)
+        _all_to_all(rcodes, codes, group)
+    else:
+        rcodes = codes
+    slab = shard.resolve(rcodes)
+    if world > 1:
+        full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
+        _all_gather_into(full, slab, group)
+    else:
+        full = slab
+    return shard.finish(full, to_host)
+
+
 def view_range(n_views_total, rank, world):
     """Contiguous, rank-ordered split of the processed camera list."""
     base, rem = divmod(n_views_total, world)

@@ -163,6 +163,28 @@ class Context:
     def vote_slab_reduce(self, recv_counts_ptr, recv_first_ptr):
         check(self._lib.gsx_vote_slab_reduce(self.h, C.c_void_p(recv_counts_ptr), C.c_void_p(recv_first_ptr)), self.h)
 
+    def vote_flush_counts(self):
+        check(self._lib.gsx_vote_flush_counts(self.h), self.h)
+
+    def vote_slab_totals(self, recv_counts_ptr):
+        check(self._lib.gsx_vote_slab_totals(self.h, C.c_void_p(recv_counts_ptr)), self.h)
+
+    def cand_device(self):
+        n = C.c_int64()
+        p = self._lib.gsx_vote_cand_device(self.h, C.byref(n))
+        return p, n.value
+
+    def vote_tie_codes(self, cand_all_ptr):
+        check(self._lib.gsx_vote_tie_codes(self.h, C.c_void_p(cand_all_ptr)), self.h)
+
+    def codes_device(self):
+        n = C.c_int64()
+        p = self._lib.gsx_vote_codes_device(self.h, C.byref(n))
+        return p, n.value
+
+    def vote_tie_resolve(self, recv_codes_ptr):
+        check(self._lib.gsx_vote_tie_resolve(self.h, C.c_void_p(recv_codes_ptr)), self.h)
+
     def vote_labels_from_sorted(self, sorted_ptr, to_host=True):
         out = np.empty(self.n, np.int32) if to_host else None
         check(self._lib.gsx_vote_labels_from_sorted(self.h, C.c_void_p(sorted_ptr), out.ctypes.data if to_host else None),

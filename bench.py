@@ -45,8 +45,9 @@ def parse():
                     help="experiment: pre-sort the Gaussians on the host before upload")
     ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
     ap.add_argument("--render-splats", type=int, default=3_000_000)
-    ap.add_argument("--exchange", default="a2a", choices=["a2a", "allreduce"],
-                    help="multi-GPU protocol: all-to-all + slab arg-max (v2) or all-reduce of the histogram (v1)")
+    ap.add_argument("--exchange", default="sparse", choices=["sparse", "a2a", "allreduce"],
+                    help="multi-GPU protocol: counts-only all-to-all + sparse tie pass (v3), all-to-all of both planes "
+                         "(v2) or all-reduce of the histogram (v1)")
     ap.add_argument("--force-exchange-path", action="store_true",
                     help="N=1 only: run the multi-GPU code path (planes kernel + slab reduce) on one GPU to time its kernels")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -139,7 +140,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    use_a2a = (world > 1 or args.force_exchange_path) and args.exchange == "a2a" and V <= 255
+    use_a2a = (world > 1 or args.force_exchange_path) and args.exchange in ("a2a", "sparse") and V <= 255
+    use_sparse = use_a2a and args.exchange == "sparse"
     if use_a2a:
         pkg.dist.configure_a2a(ctx, world)
     ctx.upload_positions(pos)
@@ -154,12 +156,14 @@ def main():
     ctx.synchronize()
     setup_s = time.time() - t0
 
-    shard = pkg.dist.GpuSlabShard(ctx) if use_a2a else pkg.dist.GpuVoteShard(ctx)
+    shard = (pkg.dist.GpuSparseShard(ctx) if use_sparse else pkg.dist.GpuSlabShard(ctx)) if use_a2a else pkg.dist.GpuVoteShard(ctx)
 
     def step():
         ctx.vote_rewind()
         if world == 1 and not args.force_exchange_path:
             ctx.vote_finalize(to_host=False)      # fused kernel -> int32 labels in HBM
+        elif use_sparse:
+            pkg.dist.exchange_labels_sparse(shard, to_host=False)
         elif use_a2a:
             pkg.dist.exchange_labels_a2a(shard, to_host=False)
         else:
@@ -190,7 +194,7 @@ def main():
     value = n * total_views / (elapsed / args.steps)
 
     # ---- dominant kernel: HIP-event time on the ctx stream, algorithmic bytes / time ------------------
-    kname = "vote_fused_labels" if (world == 1 and not args.force_exchange_path) else "vote_fused_planes"
+    kname = "vote_fused_labels" if (world == 1 and not args.force_exchange_path) else ("vote_fused_counts" if use_sparse else "vote_fused_planes")
     roofline = None
     vis_frac = None
     if rank == 0:
@@ -210,7 +214,8 @@ def main():
                 alg = 12.0 * n + 1.0 * n_vis + 4.0 * n + 192.0 * V
             else:
                 esz = 1 if (use_a2a or total_views <= 255) else 2
-                alg = 12.0 * n + 1.0 * n_vis + 2.0 * esz * (args.classes + 1) * n + 192.0 * V
+                planes = 1.0 if use_sparse else 2.0
+                alg = 12.0 * n + 1.0 * n_vis + planes * esz * (args.classes + 1) * n + 192.0 * V
             achieved = alg / (k_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -258,7 +263,8 @@ def main():
                                    f"BASELINE configs[{2 if world == 1 else 3}]",
                        "gaussians": n, "views_per_gpu": V, "views_total": total_views, "width": W, "height": H,
                        "classes": args.classes, "parallelism": f"views sharded x{world}",
-                       "exchange": None if world == 1 else ("all_to_all + slab arg-max + all_gather(labels)" if use_a2a else
+                       "exchange": None if world == 1 else ("all_to_all(counts) + sparse tie pass + all_gather(labels)" if use_sparse else
+                                                            "all_to_all + slab arg-max + all_gather(labels)" if use_a2a else
                                                             "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"),
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),

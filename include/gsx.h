@@ -157,6 +157,26 @@ int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out);
  *   exchange 2:  all_gather of the slab labels -> slabs*sn int32 in Morton (upload) order
  *   rank-local:  gsx_vote_labels_from_sorted(all_labels_dev, labels_out): back to the caller's order */
 void* gsx_vote_first_device(gsx_ctx* ctx, int64_t* n_int32_words);
+/* ---- protocol v3: counts-only all-to-all + a sparse tie pass (same options as v2) -------------------------
+ * Only the COUNT plane crosses the fabric (half of v2's bytes) and it comes out of the fast u8-histogram
+ * kernel; first-view information is computed afterwards, for the tied Gaussians only.
+ *   rank-local:  gsx_vote_flush_counts        u8 count plane [slab][bins][sn] at gsx_vote_counts_device()
+ *   exchange 1:  all_to_all over the count plane
+ *   rank-local:  gsx_vote_slab_totals(recv)   unique maximum -> label; otherwise label -2 and the set of
+ *                                             max-count bins as a bit mask, u32 [8][sn] at gsx_vote_cand_device()
+ *   exchange 2:  all_gather of the masks -> [slab][8][sn]
+ *   rank-local:  gsx_vote_tie_codes(masks)    tied Gaussians only: walk this rank's views in forward order, stop
+ *                                             at the first one voting a candidate -> u16 codes [slab][sn]
+ *                                             ((255 - local view) << 8 | bin) at gsx_vote_codes_device()
+ *   exchange 3:  all_to_all over the codes (2 bytes per Gaussian)
+ *   rank-local:  gsx_vote_tie_resolve(recv)   lowest rank with a code wins = globally earliest view
+ *   exchange 4:  all_gather of the slab labels (gsx_vote_keys_device), then gsx_vote_labels_from_sorted */
+int gsx_vote_flush_counts(gsx_ctx* ctx);
+int gsx_vote_slab_totals(gsx_ctx* ctx, const void* recv_counts_dev);
+void* gsx_vote_cand_device(gsx_ctx* ctx, int64_t* n_int32_words);
+int gsx_vote_tie_codes(gsx_ctx* ctx, const void* cand_all_dev);
+void* gsx_vote_codes_device(gsx_ctx* ctx, int64_t* n_int32_words);
+int gsx_vote_tie_resolve(gsx_ctx* ctx, const void* recv_codes_dev);
 int64_t gsx_vote_slab_size(const gsx_ctx* ctx);
 int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev);
 int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out);

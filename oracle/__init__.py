@@ -358,3 +358,52 @@ class NumpySlabShard:
 
     def finish(self, all_labels):
         return np.asarray(all_labels[:self.n], dtype=np.int32)
+
+
+class NumpySparseShard(NumpySlabShard):
+    """CPU stand-in for one rank of exchange protocol v3 (dist.exchange_labels_sparse), gloo tests only."""
+
+    def __init__(self, positions, cams, segs, img_sizes, n_classes, world):
+        super().__init__(positions, cams, segs, img_sizes, n_classes, world)
+        # per-view bins of this rank, forward order, for the tie walk
+        self.view_bins = np.stack([view_bins(positions, c, s, z) for c, s, z in zip(cams, segs, img_sizes)]) \
+            if len(cams) else np.zeros((0, self.n), np.int32)
+        self.labels = None
+
+    def totals(self, recv_cnt):
+        S, bins, sn = self.world, self.bins, self.sn
+        total = recv_cnt.reshape(S, bins, sn).astype(np.int64).sum(0)
+        M = total.max(0)
+        cand = (total == M[None]) & (M[None] > 0)                               # (bins, sn)
+        n_max = cand.sum(0)
+        first = cand.argmax(0)
+        self.labels = np.where(n_max == 0, -1, np.where(n_max == 1, first - 1, -2)).astype(np.int32)
+        words = np.zeros((8, sn), np.uint32)
+        for b in range(bins):
+            words[b >> 5] |= (cand[b].astype(np.uint32) << np.uint32(b & 31))
+        return words
+
+    def tie_codes(self, cand_all):
+        S, sn = self.world, self.sn
+        masks = cand_all.reshape(S, 8, sn)
+        codes = np.zeros(S * sn, np.uint16)
+        for i in range(self.n):
+            slab, j = divmod(i, sn)
+            m = masks[slab, :, j]
+            if sum(bin(int(w)).count("1") for w in m) < 2:
+                continue
+            for v in range(self.view_bins.shape[0]):
+                b = int(self.view_bins[v, i])
+                if b >= 0 and (int(m[b >> 5]) >> (b & 31)) & 1:
+                    codes[i] = ((255 - v) << 8) | b
+                    break
+        return codes
+
+    def resolve(self, recv_codes):
+        S, sn = self.world, self.sn
+        rc = recv_codes.reshape(S, sn)
+        out = self.labels.copy()
+        for i in np.nonzero(out == -2)[0]:
+            hit = np.nonzero(rc[:, i])[0]
+            out[i] = (int(rc[hit[0], i]) & 0xff) - 1 if len(hit) else -1
+        return out

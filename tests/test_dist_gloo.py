@@ -49,6 +49,39 @@ def test_two_rank_exchange_equals_reference_labels(case_idx, wide):
     assert all(ok for _, ok, _ in res), res
 
 
+def _worker_sparse(rank, world, port, case_idx, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+        name, pos, cams, segs, sizes, labels = golden_assign_cases()[case_idx]
+        lo, hi = pkg.dist.view_range(len(cams), rank, world)
+        shard = oracle.NumpySparseShard(pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], 150, world)
+        got = pkg.dist.exchange_labels_sparse(pkg.dist.HostSparseShard(shard))
+        q.put((rank, bool(np.array_equal(got, labels)), int((got != labels).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_idx,world", [(2, 2), (3, 2), (4, 2), (3, 3)])
+def test_sparse_tie_exchange_equals_reference_labels(case_idx, world):
+    """Protocol v3 (counts-only all-to-all + sparse tie pass), incl. the ties fixture and 3 ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + case_idx * 13 + world) % 2000
+    procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, case_idx, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
 def _worker_a2a(rank, world, port, case_idx, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

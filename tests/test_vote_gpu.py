@@ -243,6 +243,59 @@ def test_all_to_all_exchange_on_one_gpu(gsx):
                 c.close()
 
 
+def test_sparse_tie_exchange_on_one_gpu(gsx):
+    """Exchange protocol v3 with three contexts playing three ranks (collectives done by hand with torch);
+    every intermediate (count plane, candidate masks, tie codes, slab labels) is compared with the numpy
+    stand-in, and the final labels with the oracle.  Few classes -> most Gaussians are tied."""
+    import torch
+    n, V, world = 40_001, 13, 3
+    pos, cams, segs = scene.make_scene(n, V, 320, 180, n_classes=5, config_id=41, convention="w2c")
+    sizes = [(320, 180)] * V
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    for spatial in (0, 1):
+        ctxs, shards, ref = [], [], []
+        try:
+            for r in range(world):
+                c = gsx.Context(0)
+                ctxs.append(c)
+                c.set_option("spatial_sort", spatial)
+                gsx.dist.configure_a2a(c, world)
+                lo, hi = gsx.dist.view_range(V, r, world)
+                run_gpu(c, pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], n_classes=5, first=lo, total=V)
+                shards.append(gsx.dist.GpuSparseShard(c))
+                if spatial == 0:
+                    ref.append(oracle.NumpySparseShard(pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], 5, world))
+            cnts = [sh.counts() for sh in shards]
+            chunk = cnts[0].numel() // world
+            a2a = lambda parts, r, ch: torch.cat([parts[s][r * ch:(r + 1) * ch] for s in range(world)])
+            cands = []
+            for r in range(world):
+                rc = a2a(cnts, r, chunk)
+                cands.append(shards[r].totals(rc).clone())
+                if spatial == 0:
+                    assert np.array_equal(cnts[r].cpu().numpy().view(np.uint8), ref[r].cnt.reshape(-1))
+                    assert np.array_equal(cands[r].cpu().numpy().view(np.uint32).reshape(8, -1), ref[r].totals(rc.cpu().numpy().view(np.uint8)))
+            cand_all = torch.cat(cands)
+            codes = [shards[r].tie_codes(cand_all).clone() for r in range(world)]
+            cchunk = codes[0].numel() // world
+            slabs = []
+            for r in range(world):
+                rcodes = a2a(codes, r, cchunk)
+                if spatial == 0:
+                    assert np.array_equal(codes[r].cpu().numpy().view(np.uint16), ref[r].tie_codes(cand_all.cpu().numpy().view(np.uint32)))
+                slabs.append(shards[r].resolve(rcodes).clone())
+            full = torch.cat(slabs)
+            tied = sum(int((t == -2).sum()) for t in slabs)
+            assert tied == 0
+            for r in range(world):
+                assert np.array_equal(shards[r].finish(full), want), (spatial, r)
+            if spatial == 0:
+                assert (ref[0].labels == -2).mean() > 0.05          # the scene really exercises the tie pass
+        finally:
+            for c in ctxs:
+                c.close()
+
+
 def test_seg_dtypes_and_device_maps(ctx):
     import torch
     n = 10_000

@@ -13,9 +13,11 @@ for o in "" "--opt xcd_swizzle=0" "--opt seg_tiled=0" "--opt spatial_sort=0" "";
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --render-views 0 $o 2>/dev/null \
     | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$o', d['ms_per_step'], d['roofline']['kernel_ms'], d['value'])" | tee -a $OUT/sweep.log
 done
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --gaussians 1000000 --views 40 > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank a2a rehearsal rc=$?"
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29631 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --gaussians 1000000 --views 40 > $OUT/bench_2rank_gloo_v3.json 2> $OUT/bench_2rank_gloo_v3.err; echo "2-rank sparse rehearsal rc=$?"
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29635 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --exchange a2a --gaussians 1000000 --views 40 > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err; echo "2-rank a2a rehearsal rc=$?"
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29633 bench.py --gpus 2 --steps 3 --warmup 1 --backend gloo --exchange allreduce --gaussians 1000000 --views 40 > $OUT/bench_2rank_gloo_v1.json 2> $OUT/bench_2rank_gloo_v1.err; echo "2-rank allreduce rehearsal rc=$?"
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --render-views 0 --force-exchange-path > $OUT/bench_exchange_path.json 2>/dev/null; echo "exchange-path rc=$?"
+timeout -k 10 300 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --render-views 0 --force-exchange-path --exchange a2a > $OUT/bench_exchange_path_v2.json 2>/dev/null; echo "exchange-path v2 rc=$?"
 timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/calib_fetch -- $ROOT/tools/calib_gather > $OUT/calib_fetch.log 2>&1
