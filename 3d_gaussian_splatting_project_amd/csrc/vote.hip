@@ -11,9 +11,17 @@
 //   seg pool       u8 maps, value = label+1 (bin index), one after another, each stored as 16x8-pixel
 //                  tiles of 128 B (one L2 line): the pixels a wave gathers are a compact patch, so they
 //                  fall into few lines; 1 B gathers
-//   planes         cnt[bins][n_pad], fv[bins][n_pad]  u8 (total_views <= 255) or u16: bin-major so
-//                  that a wave's 64 Gaussians touch 64 consecutive elements of a row
-//   keys, labels   int32[n_pad]
+//   planes         cnt[slab][bins][sn], fv[slab][bins][sn]  u8 or u16 (16 bit only for the all-reduce
+//                  protocol with > 255 views in total): bin-major so that a wave's 64 Gaussians touch 64
+//                  consecutive elements of a row; slab = one rank's share in the all-to-all protocols
+//                  (a single slab is plain [bins][n_pad])
+//   keys, labels   int32[n_pad]; cand u32[8][sn]; codes u16[n_pad] (exchange protocol v3)
+//
+// Kernels
+//   vote_fused_labels_kernel   single GPU: all staged views in one launch, labels straight out
+//   vote_fused_planes_kernel   multi-GPU v1/v2 (and > 255 views): count + first-view planes
+//   vote_fused_counts_kernel   multi-GPU v3: count plane only; vote_slab_totals / vote_tie / vote_tie_resolve
+//   vote_keys / vote_labels / vote_slab_reduce / unpermute_labels   the rank-local ends of the protocols
 //
 // Kernel design (Gaussian-major, all staged views in one launch)
 //   one thread = one Gaussian; it walks the views in REVERSE order and keeps its private vote
