@@ -229,6 +229,15 @@ def main():
                         "kernel_ms": round(k_ms, 4), "launches": launches, "algorithmic_bytes": int(alg),
                         "note": "fp64-VALU/gather-latency bound kernel; see DESIGN.md §6"}
 
+    exchange_ms = None
+    if rank == 0 and not args.no_profile and (world > 1 or args.force_exchange_path):
+        exchange_ms = {}
+        for k in ("vote_fused_counts", "vote_fused_planes", "vote_slab_totals", "vote_tie", "vote_tie_resolve", "vote_slab_reduce",
+                  "vote_keys", "vote_labels"):
+            cnt_k, ms_k = ctx.profile_get(k)
+            if cnt_k:
+                exchange_ms[k] = round(ms_k / cnt_k, 4)
+
     # ---- CPU baseline: the oracle (C port of the reference loop) on a bounded sample ---------------------
     cpu = None
     if keep_host:
@@ -272,6 +281,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "render": render,
+            "exchange_kernels_ms": exchange_ms,
         }
         print(json.dumps(out), flush=True)
     ctx.close()
