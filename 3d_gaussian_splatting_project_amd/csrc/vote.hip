@@ -339,37 +339,41 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
 // v3, slab owner: sum the S ranks' counters per bin; a unique maximum is the label, otherwise the Gaussian is
 // TIED (label -2 for now) and the set of max-count bins goes out as a bit mask, cand[word][sn], 8 words.
 static constexpr int kCandWords = 8;  // bins <= 256
-static constexpr int kTotalsThreads = 64;
-// One thread owns 4 consecutive Gaussians (every plane row is read as coalesced dwords: 256 B per wave
-// instruction instead of 64 single bytes) and parks its 4 x bins totals in LDS, so the planes are read once.
-__global__ __launch_bounds__(kTotalsThreads) void vote_slab_totals_kernel(const uint8_t* __restrict__ rcnt, int S, int bins,
-                                                                          long long sn, int* __restrict__ slab_labels,
-                                                                          uint32_t* __restrict__ cand) {
-    extern __shared__ uint32_t tl[];  // [bins][64 threads][2 dwords] = 4 x u16 totals
-    const long long i4 = ((long long)blockIdx.x * kTotalsThreads + threadIdx.x) * 4;
-    if (i4 >= sn) return;  // sn is a multiple of 256: whole blocks only
-    unsigned M[4] = {0, 0, 0, 0};
-    for (int b = 0; b < bins; ++b) {
-        unsigned t[4] = {0, 0, 0, 0};
-        for (int r = 0; r < S; ++r) {
-            const uint32_t w = *reinterpret_cast<const uint32_t*>(rcnt + ((long long)r * bins + b) * sn + i4);
+// One thread owns 4 consecutive Gaussians: every plane row is read as coalesced dwords (256 B per wave
+// instruction instead of 64 single bytes).  Two passes over the slab (maximum, then masks); parking the
+// totals in LDS instead was measured 2x slower (77 KB per wave leaves 2 waves per CU).
+__device__ __forceinline__ void slab_totals4(const uint8_t* __restrict__ rcnt, int S, int bins, long long sn, long long i4, int b,
+                                             unsigned t[4]) {
+    t[0] = t[1] = t[2] = t[3] = 0;
+    for (int r = 0; r < S; ++r) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(rcnt + ((long long)r * bins + b) * sn + i4);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) t[k] += (w >> (8 * k)) & 0xffu;
-        }
+        for (int k = 0; k < 4; ++k) t[k] += (w >> (8 * k)) & 0xffu;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t* __restrict__ rcnt, int S, int bins,
+                                                                  long long sn, int* __restrict__ slab_labels,
+                                                                  uint32_t* __restrict__ cand) {
+    const long long i4 = ((long long)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i4 >= sn) return;
+    unsigned M[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int b = 0; b < bins; ++b) {
+        unsigned t[4];
+        slab_totals4(rcnt, S, bins, sn, i4, b, t);
 #pragma unroll
         for (int k = 0; k < 4; ++k) M[k] = max(M[k], t[k]);
-        uint32_t* slot = tl + ((size_t)b * kTotalsThreads + threadIdx.x) * 2;
-        slot[0] = t[0] | (t[1] << 16);
-        slot[1] = t[2] | (t[3] << 16);
     }
     int n_max[4] = {0, 0, 0, 0}, first_bin[4] = {-1, -1, -1, -1};
     for (int w = 0; w < kCandWords; ++w) {
         uint32_t word[4] = {0, 0, 0, 0};
+#pragma unroll 4
         for (int bb = 0; bb < 32; ++bb) {
             const int b = w * 32 + bb;
             if (b >= bins) break;
-            const uint32_t* slot = tl + ((size_t)b * kTotalsThreads + threadIdx.x) * 2;
-            const unsigned t[4] = {slot[0] & 0xffffu, slot[0] >> 16, slot[1] & 0xffffu, slot[1] >> 16};
+            unsigned t[4];
+            slab_totals4(rcnt, S, bins, sn, i4, b, t);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (M[k] > 0 && t[k] == M[k]) {
@@ -1042,13 +1046,9 @@ int vote_slab_totals(Ctx* c, const void* recv_cnt) {
     GSX_HIP(c, hipSetDevice(c->device));
     GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)c->n_pad));
     GSX_HIP(c, c->cand.ensure(sizeof(uint32_t) * kCandWords * (size_t)c->sn));
-    const size_t tl_bytes = (size_t)c->bins * kTotalsThreads * 8;
-    int rc = set_lds(c, vote_slab_totals_kernel, tl_bytes);
-    if (rc) return rc;
     ProfScope ps(c, "vote_slab_totals");
-    hipLaunchKernelGGL(vote_slab_totals_kernel, dim3((unsigned)(c->sn / (4 * kTotalsThreads))), dim3(kTotalsThreads), tl_bytes,
-                       c->stream, (const uint8_t*)recv_cnt, c->slabs, c->bins, (long long)c->sn, c->keys.as<int>(),
-                       c->cand.as<uint32_t>());
+    hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(c->sn / 4)), dim3(kBlock), 0, c->stream, (const uint8_t*)recv_cnt,
+                       c->slabs, c->bins, (long long)c->sn, c->keys.as<int>(), c->cand.as<uint32_t>());
     GSX_HIP(c, hipGetLastError());
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     return GSX_OK;
