@@ -119,7 +119,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
-                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->tie_list, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
+                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();

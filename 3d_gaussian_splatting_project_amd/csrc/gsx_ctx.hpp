@@ -129,7 +129,6 @@ struct Ctx {
     bool planes_stale = false;  // planes hold a rewound run's votes; the next fresh flush overwrites them
     DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
     DevBuf keys, labels;        // [n_pad] int32
-    DevBuf tie_list;            // exchange v3: compacted indices of the tied Gaussians (+ their count)
     DevBuf cand, codes;         // exchange v3: candidate masks u32[8][sn] of this slab; tie codes u16[n_pad]
     bool labels_valid = false;
 

@@ -391,56 +391,36 @@ __global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t*
     *reinterpret_cast<int4*>(slab_labels + i4) = make_int4(lab[0], lab[1], lab[2], lab[3]);
 }
 
-// v3, every rank, step 1: compact the indices of the TIED Gaussians (two or more candidate bins) with a
-// wave ballot + prefix count and one atomic per wave, so that the tie walk below runs on full waves.
-// cand_all: [S][kCandWords][sn] (all-gathered masks).
-__global__ __launch_bounds__(kBlock) void vote_tie_compact_kernel(const uint32_t* __restrict__ cand_all, long long n,
-                                                                  long long sn, uint32_t* __restrict__ list,
-                                                                  unsigned* __restrict__ count) {
-    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    bool tied = false;
-    if (i < n) {
-        const long long slab = i / sn, j = i - slab * sn;
-        int pop = 0;
-#pragma unroll
-        for (int w = 0; w < kCandWords; ++w) pop += __popc(cand_all[(slab * kCandWords + w) * sn + j]);
-        tied = pop >= 2;
-    }
-    const unsigned long long m = __ballot(tied);
-    if (m == 0ull) return;
-    const int lane = threadIdx.x & 63;
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(count, (unsigned)__popcll(m));
-    base = __shfl(base, 0);
-    if (tied) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)i;
-}
-
-// step 2: walk this rank's views in FORWARD order for every listed Gaussian and stop at the first one that
-// votes a candidate: code = (255 - local view index) << 8 | bin, 0 if none.  codes: u16 [S][sn], slab-major.
+// v3, every rank: for each TIED Gaussian (two or more candidate bins) walk this rank's views in FORWARD order
+// and stop at the first one that votes a candidate: code = (255 - local view index) << 8 | bin, 0 if none.
+// cand_all: [S][kCandWords][sn] (all-gathered masks); codes: u16 [S][sn], slab-major.
 __global__ __launch_bounds__(kBlock) void vote_tie_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                           const uint32_t* __restrict__ cand_all, long long sn,
-                                                          const uint32_t* __restrict__ list,
-                                                          const unsigned* __restrict__ count,
                                                           uint16_t* __restrict__ codes) {
-    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (g >= (long long)*count) return;
-    const long long i = list[g];
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    if (i >= p.n) return;
     const long long slab = i / sn, j = i - slab * sn;
     uint32_t mask[kCandWords];
+    int pop = 0;
 #pragma unroll
-    for (int w = 0; w < kCandWords; ++w) mask[w] = cand_all[(slab * kCandWords + w) * sn + j];
+    for (int w = 0; w < kCandWords; ++w) {
+        mask[w] = cand_all[(slab * kCandWords + w) * sn + j];
+        pop += __popc(mask[w]);
+    }
     unsigned code = 0;
-    const double X = (double)p.x[i], Y = (double)p.y[i], Z = (double)p.z[i];
-    for (int v = 0; v < p.nviews; ++v) {
-        const long long off = seg_index<false>(views + v, X, Y, Z);
-        if (off < 0) continue;
-        const unsigned b = p.pool[off];
-        uint32_t word = 0;
+    if (pop >= 2) {
+        const double X = (double)p.x[i], Y = (double)p.y[i], Z = (double)p.z[i];
+        for (int v = 0; v < p.nviews; ++v) {
+            const long long off = seg_index<false>(views + v, X, Y, Z);
+            if (off < 0) continue;
+            const unsigned b = p.pool[off];
+            uint32_t word = 0;
 #pragma unroll
-        for (int w = 0; w < kCandWords; ++w) word = (b >> 5) == (unsigned)w ? mask[w] : word;
-        if ((word >> (b & 31u)) & 1u) {
-            code = ((unsigned)(255 - v) << 8) | b;
-            break;
+            for (int w = 0; w < kCandWords; ++w) word = (b >> 5) == (unsigned)w ? mask[w] : word;
+            if ((word >> (b & 31u)) & 1u) {
+                code = ((unsigned)(255 - v) << 8) | b;
+                break;
+            }
         }
     }
     codes[i] = (uint16_t)code;  // == codes[slab][j]: n_pad = S * sn
@@ -1079,19 +1059,15 @@ int vote_tie_codes(Ctx* c, const void* cand_all) {
     if (!cand_all) return fail(c, GSX_E_INVALID, "vote_tie_codes: NULL argument");
     GSX_HIP(c, hipSetDevice(c->device));
     const size_t bytes = sizeof(uint16_t) * (size_t)c->n_pad;
-    GSX_HIP(c, c->codes.ensure(bytes));
-    GSX_HIP(c, hipMemsetAsync(c->codes.p, 0, bytes, c->stream));  // untied Gaussians: code 0
+    if (bytes > c->codes.cap) {
+        GSX_HIP(c, c->codes.ensure(bytes));
+        GSX_HIP(c, hipMemsetAsync(c->codes.p, 0, bytes, c->stream));
+    }
     if (c->n > 0) {
-        GSX_HIP(c, c->tie_list.ensure(sizeof(uint32_t) * (size_t)c->n + 16));
-        unsigned* count = reinterpret_cast<unsigned*>(c->tie_list.as<uint32_t>() + c->n);
-        GSX_HIP(c, hipMemsetAsync(count, 0, sizeof(unsigned), c->stream));
         FusedParams p = fused_params(c, 1);
         ProfScope ps(c, "vote_tie");
-        hipLaunchKernelGGL(vote_tie_compact_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, (const uint32_t*)cand_all,
-                           (long long)c->n, (long long)c->sn, c->tie_list.as<uint32_t>(), count);
         hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, p, p.views,
-                           (const uint32_t*)cand_all, (long long)c->sn, c->tie_list.as<uint32_t>(), count,
-                           c->codes.as<uint16_t>());
+                           (const uint32_t*)cand_all, (long long)c->sn, c->codes.as<uint16_t>());
         GSX_HIP(c, hipGetLastError());
     }
     GSX_HIP(c, hipStreamSynchronize(c->stream));
