@@ -391,6 +391,8 @@ __global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t*
     *reinterpret_cast<int4*>(slab_labels + i4) = make_int4(lab[0], lab[1], lab[2], lab[3]);
 }
 
+// (A wave-ballot compaction of the tied Gaussians in front of this kernel was measured: 0.90 ms vs 0.59 ms —
+// the atomically ordered list loses the Morton locality of the gathers; not kept.)
 // v3, every rank: for each TIED Gaussian (two or more candidate bins) walk this rank's views in FORWARD order
 // and stop at the first one that votes a candidate: code = (255 - local view index) << 8 | bin, 0 if none.
 // cand_all: [S][kCandWords][sn] (all-gathered masks); codes: u16 [S][sn], slab-major.
