@@ -38,7 +38,25 @@ __device__ __forceinline__ void blend_one(Accum& acc, float fxp, float fyp, cons
     }
 }
 
+// Longest-list-first launch order: the kernel ends when its slowest tile does (a tile that never
+// saturates walks its whole list), so the long tiles must not be dealt last.  key = 63 - 2*log2(len)
+// rounded to half octaves: one 6-bit radix pass over the tiles.
+__global__ __launch_bounds__(256) void tile_order_key_kernel(const int2* __restrict__ ranges, int ntiles,
+                                                             uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntiles) return;
+    const unsigned len = (unsigned)(ranges[t].y - ranges[t].x);
+    unsigned k = 0;
+    if (len) {
+        const unsigned lg = 31u - (unsigned)__clz(len);
+        k = 2u * lg + ((len >> (lg ? lg - 1 : 0)) & 1u) + 1u;
+    }
+    keys[t] = 63u - min(k, 63u);
+    vals[t] = (uint32_t)t;
+}
+
 __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __restrict__ ranges,
+                                                              const uint32_t* __restrict__ tile_order,
                                                               const uint32_t* __restrict__ vals,
                                                               const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
@@ -49,7 +67,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     __shared__ float4 s0[kBlendThreads];
     __shared__ float4 s1[kBlendThreads];
     __shared__ float2 s2[kBlendThreads];
-    const int tile = blockIdx.x;
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (threadIdx.x & (kTile - 1));
     const int py = ty * kTile + (threadIdx.x >> 4);
@@ -91,8 +109,21 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
 int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
                  unsigned long long* consumed_dev) {
     const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
+    const int ntiles = tiles_x * tiles_y;
+    const uint32_t* order = nullptr;
+    if (c->opt_tile_lpt && c->r_P > 0 && ntiles > 256) {
+        GSX_HIP(c, c->r_tile_order.ensure(sizeof(uint32_t) * 4 * (size_t)ntiles));
+        uint32_t* k0 = c->r_tile_order.as<uint32_t>();
+        uint32_t *v0 = k0 + ntiles, *k1 = v0 + ntiles, *v1 = k1 + ntiles;
+        hipLaunchKernelGGL(tile_order_key_kernel, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream, c->r_ranges.as<int2>(),
+                           ntiles, k0, v0);
+        int where = 0;
+        int rc = radix_sort_pairs(c, k0, v0, k1, v1, ntiles, 6, &where);
+        if (rc) return rc;
+        order = where ? v1 : v0;
+    }
     ProfScope ps(c, "render_blend");
-    hipLaunchKernelGGL(blend_kernel, dim3(tiles_x * tiles_y), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), vals,
+    hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                        c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
                        (long long)c->rn, consumed_dev, c->r_image.as<float4>());
     GSX_HIP(c, hipGetLastError());

@@ -121,7 +121,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
                            &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
-                           &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
+                           &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -144,6 +144,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     if (k == "spatial_sort") c->opt_spatial_sort = value != 0;
     else if (k == "xcd_swizzle") c->opt_xcd_swizzle = value != 0;
     else if (k == "seg_tiled") c->opt_seg_tiled = value != 0;
+    else if (k == "tile_lpt") c->opt_tile_lpt = value != 0;
     else if (k == "exchange_slabs") {
         if (value < 1 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: exchange_slabs must be in [1,64]");
         c->opt_slabs = (int)value;

@@ -105,6 +105,7 @@ struct Ctx {
     int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
     int opt_local_codes = 0;   // see Ctx::local_codes
     int opt_lds_batch = 0;     // read a chunk's LDS counters in one round trip (repeats resolved in registers)
+    int opt_tile_lpt = 1;      // rasterizer: launch the tiles with the longest lists first
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_shared_rcp = 0;    // one reciprocal chain for the two IEEE divisions of a projection (measured 2 % slower)
 
@@ -144,6 +145,7 @@ struct Ctx {
     DevBuf r_ranges, r_small, r_scan;
     DevBuf r_depth, r_bucket, r_rect, r_count, r_offset, r_rec0, r_rec1, r_rec2;
     DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
+    DevBuf r_tile_order;                 // blend launch order (longest list first)
     int r_sorted_in = 0;
     uint32_t r_P = 0;                    // (tile, splat) pairs of the last view
     unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)
