@@ -265,6 +265,36 @@ __global__ __launch_bounds__(kRB) void depth_kernel(const uint4* __restrict__ te
     }
 }
 
+// Exact tile culling.  A pixel takes a fragment of the splat iff q(d) = (d.g0)^2 + (d.g1)^2 <= 4 for its
+// centre's offset d from the splat centre (A = -q, `discard` if A < -4).  q is a convex quadratic, so its
+// minimum over a tile's rectangle of pixel centres is 0 (centre inside) or lies on one of the 4 edges, where
+// q is a 1-D quadratic.  A tile is kept iff that minimum <= 4.04 (1 % of slack over the fp32 rounding of
+// the per-pixel evaluation): elongated and diagonal splats lose most of their bounding-box tiles.
+__device__ __forceinline__ float edge_min_q(float ax, float ay, float bx, float by, float g0x, float g0y, float g1x,
+                                            float g1y) {
+    // p(t) = a + t (b - a), t in [0,1]; u(t) = p.g0, v(t) = p.g1 are affine in t
+    const float u0 = ax * g0x + ay * g0y, v0 = ax * g1x + ay * g1y;
+    const float du = (bx - ax) * g0x + (by - ay) * g0y, dv = (bx - ax) * g1x + (by - ay) * g1y;
+    const float den = du * du + dv * dv;
+    float t = den > 0.0f ? -(u0 * du + v0 * dv) / den : 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float u = u0 + t * du, v = v0 + t * dv;
+    return u * u + v * v;
+}
+
+__device__ __forceinline__ bool tile_touches(float cx, float cy, float g0x, float g0y, float g1x, float g1y, float H,
+                                             uint32_t tx, uint32_t ty) {
+    // rectangle of the tile's pixel centres, relative to the splat centre, GL window coordinates (y up)
+    const float x0 = (float)(tx * 16u) + 0.5f - cx, x1 = x0 + 15.0f;
+    const float y1 = H - ((float)(ty * 16u) + 0.5f) - cy, y0 = y1 - 15.0f;
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return true;
+    float q = edge_min_q(x0, y0, x1, y0, g0x, g0y, g1x, g1y);
+    q = fminf(q, edge_min_q(x0, y1, x1, y1, g0x, g0y, g1x, g1y));
+    q = fminf(q, edge_min_q(x0, y0, x0, y1, g0x, g0y, g1x, g1y));
+    q = fminf(q, edge_min_q(x1, y0, x1, y1, g0x, g0y, g1x, g1y));
+    return !(q > 4.04f);  // NaN keeps the tile
+}
+
 // bucket (gs.js:443-447) + vertex shader (gs.js:696-750) + tile rectangle
 __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
                                                           const int* __restrict__ depth, const int* __restrict__ minmax,
@@ -272,7 +302,7 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
                                                           float4* __restrict__ rec0, float4* __restrict__ rec1,
                                                           float2* __restrict__ rec2, uint32_t* __restrict__ bucket,
                                                           uint32_t* __restrict__ tile_rect, uint32_t* __restrict__ tile_count,
-                                                          int* __restrict__ dropped) {
+                                                          int* __restrict__ dropped, int exact_cull) {
     const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
     if (i >= n) return;
     const double minDepth = (double)minmax[0], maxDepth = (double)minmax[1];
@@ -359,7 +389,13 @@ __global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict
             if (x1 >= x0 && y1 >= y0 && in_range) {
                 const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
                 rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
-                count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                if (exact_cull && (tx1 > tx0 || ty1 > ty0)) {
+                    for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                        for (uint32_t tx = tx0; tx <= tx1; ++tx)
+                            count += tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, u.H, tx, ty) ? 1u : 0u;
+                } else {
+                    count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+                }
             }
         }
     }
@@ -458,15 +494,26 @@ __global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* 
                                                     const uint32_t* __restrict__ tile_rect,
                                                     const uint32_t* __restrict__ count_sorted,
                                                     const uint32_t* __restrict__ offset, int tiles_x,
-                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                    const float4* __restrict__ rec0, const float4* __restrict__ rec1, float H,
+                                                    int exact_cull, uint32_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
     const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
     if (j >= n || count_sorted[j] == 0) return;
     const uint32_t i = by_depth[j];
     const uint32_t rect = tile_rect[i];
     const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
     uint32_t o = offset[j];
+    const uint32_t o_end = o + count_sorted[j];  // never write past this splat's share
+    const bool cull = exact_cull && (tx1 > tx0 || ty1 > ty0);  // must mirror preprocess_kernel's count exactly
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    if (cull) {
+        r0 = rec0[i];
+        r1 = rec1[i];
+    }
     for (uint32_t ty = ty0; ty <= ty1; ++ty)
         for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+            if (cull && !tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, H, tx, ty)) continue;
+            if (o >= o_end) return;
             keys[o] = ty * (uint32_t)tiles_x + tx;
             vals[o] = i;
             ++o;
@@ -679,7 +726,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_depth.as<int>(), minmax, c->r_sh_valid ? c->r_sh.as<float>() : nullptr,
                                c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), c->r_bucket.as<uint32_t>(),
-                               c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2);
+                               c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2, c->opt_exact_cull);
         }
         GSX_HIP(c, hipGetLastError());
         // level 1: splats by depth bucket (stable)
@@ -712,7 +759,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             {
                 ProfScope ps(c, "render_emit");
                 hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, n, by_depth, c->r_rect.as<uint32_t>(),
-                                   count_sorted, c->r_offset.as<uint32_t>(), tiles_x, c->r_keys0.as<uint32_t>(),
+                                   count_sorted, c->r_offset.as<uint32_t>(), tiles_x, c->r_rec0.as<float4>(),
+                                   c->r_rec1.as<float4>(), (float)H, c->opt_exact_cull, c->r_keys0.as<uint32_t>(),
                                    c->r_vals0.as<uint32_t>());
             }
             GSX_HIP(c, hipGetLastError());

@@ -198,11 +198,9 @@ def main():
     roofline = None
     vis_frac = None
     if rank == 0:
-        import oracle
-        sub_idx = np.random.default_rng(5).choice(n, min(n, 20_000), replace=False)
-        sub = np.ascontiguousarray(pos[sub_idx])
-        probe = range(0, V, max(1, V // 20))
-        vis = [float((oracle.project_many(sub, cams_all[first + v])[0] >= 0).mean()) for v in probe]
+        # visible fraction of the (Gaussian, view) pairs, from the device projection kernel itself
+        probe = list(range(0, V, max(1, V // 10)))
+        vis = [float((ctx.project_all(cams_all[first + v])[0] >= 0).mean()) for v in probe]
         vis_frac = float(np.mean(vis))
     if rank == 0 and not args.no_profile:
         launches, total_ms = ctx.profile_get(kname)
