@@ -76,8 +76,10 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
  *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
- *   "exact_cull"   (default 1)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
- *                               (minimum of the quadratic over the tile), not its whole bounding box
+ *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
+ *                               (minimum of the quadratic over the tile), not its whole bounding box.  Measured
+ *                               on the 3 M-splat scene: pairs -23 %, sort -0.2 ms, but the per-splat tile loops
+ *                               diverge (+0.5 ms): off until the binning is wave-cooperative
  *   "tile_lpt"     (default 0)  rasterizer: blend the tiles with the longest splat lists first (measured:
  *                               blend -3 %, paid back by the extra ordering launches)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the

@@ -103,6 +103,29 @@ def test_big_overlapping_splats_vs_oracle(ctx):
     assert (want[..., 3] > 0.99).mean() > 0.2
 
 
+def test_render_options_do_not_change_the_frame(gsx):
+    """exact_cull / tile_lpt only change how work is binned and ordered, never a pixel."""
+    n, W, H = 20_000, 640, 360
+    xyz = scene.make_positions(n, 17)
+    a = scene.make_splat_attributes(n, 17, sh_degree=0)
+    a["scale"] += np.float32(np.log(3.0))
+    a["scale"][:, 0] += np.float32(np.log(6.0))           # elongated splats: the bounding box is mostly empty
+    cam = scene.make_cameras(5, W, H, convention="c2w")[1]
+    frames, pairs = [], []
+    for opts in ({"exact_cull": 0, "tile_lpt": 0}, {"exact_cull": 1, "tile_lpt": 0}, {"exact_cull": 1, "tile_lpt": 1}):
+        with gsx.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            frames.append(c.render_view(cam, W, H))
+            pairs.append(c.render_num_pairs())
+    want = oracle.render_scene(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cam, W, H)
+    for f in frames:
+        assert np.abs(f - want).max() <= TOL
+    assert np.array_equal(frames[1], frames[2])
+    assert pairs[1] < 0.8 * pairs[0]
+
+
 def test_fallbacks_and_empty(ctx):
     W, H = 160, 90
     cam = scene.make_cameras(3, W, H, convention="c2w")[1]
