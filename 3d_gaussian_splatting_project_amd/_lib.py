@@ -42,6 +42,7 @@ class Camera(C.Structure):
 
 _SIGS = {
     "gsx_abi_version": (C.c_int, []),
+    "gsx_device_count": (C.c_int, []),
     "gsx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "gsx_destroy": (None, [C.c_void_p]),
     "gsx_last_error": (C.c_char_p, [C.c_void_p]),

@@ -83,6 +83,11 @@ extern "C" {
 
 int gsx_abi_version(void) { return GSX_ABI_VERSION; }
 
+int gsx_device_count(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
 int gsx_create(int device_id, gsx_ctx** out) {
     if (!out) return gsx::fail(nullptr, GSX_E_INVALID, "gsx_create: out is NULL");
     *out = nullptr;

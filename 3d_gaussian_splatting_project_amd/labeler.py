@@ -25,9 +25,9 @@ class Context:
     """One GPU (gsx_ctx).  device: HIP ordinal; defaults to LOCAL_RANK or 0."""
 
     def __init__(self, device=None):
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
         self._lib = _lib.lib()
+        if device is None:  # one process per GPU: LOCAL_RANK picks it (wrapping when ranks share a GPU in a rehearsal)
+            device = int(os.environ.get("LOCAL_RANK", "0")) % max(1, self._lib.gsx_device_count())
         h = C.c_void_p()
         check(self._lib.gsx_create(int(device), C.byref(h)))
         self.h = h
@@ -253,6 +253,15 @@ class Context:
         check(self._lib.gsx_render_debug(self.h, buf.ctypes.data, order.ctypes.data, tex.ctypes.data,
                                          bk.ctypes.data if buckets else None), self.h)
         return (buf, order, tex, bk) if buckets else (buf, order, tex)
+
+    def export_splat(self, path):
+        """Write the uploaded splats as a `.splat` file: the viewer's 32-byte rows (position f32x3, exp(scale)
+        f32x3, rgba u8x4, quaternion u8x4; gs.js:237, 539-542) in importance order.  The reference viewer takes
+        such a file by drag and drop without re-parsing a 250-byte-per-vertex PLY in JavaScript."""
+        buf, _, _ = self.render_debug()
+        with open(path, "wb") as f:
+            f.write(buf.tobytes())
+        return len(buf)
 
     def sort_pairs(self, keys, values, bits=32):
         """Stable GPU radix sort by key bits [0, bits) (test hook, gsx_debug_sort_pairs)."""

@@ -9,8 +9,9 @@ they are in the reference (Hugging Face / Ultralytics models, imported lazily): 
 are fetched by name, so `--segmap_dir` lets a run consume the `<image>_segmap.npy` files the reference
 itself writes next to every segmented image (reference line 165) instead of running a network.
 
-Added flags: --segmap_dir DIR, --gpus N (informational; launch N>1 with torch.distributed.run),
---n_classes C (default: 150 for the ADE20K models, 80 for YOLO).
+Added flags: --segmap_dir DIR, --n_classes C (default: 150 for the ADE20K models, 80 for YOLO), --gpus N
+(informational).  Several GPUs: `python -m torch.distributed.run --nproc-per-node N deep_learning_segmentation.py
+...` — every rank votes its contiguous block of the cameras and the vote histogram is exchanged over RCCL.
 """
 import argparse
 import importlib
@@ -125,22 +126,62 @@ def assign_labels(gaussians, cameras, input_dir, output_dir, model_type="mask2fo
         import torch
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         processor, model = initialize_model(model_type, device)
+    world, rank = _world()
     own = ctx is None
     ctx = ctx or gsx.Context()
     try:
+        if world > 1:
+            # one process per GPU: this rank segments and votes its contiguous block of the processed cameras;
+            # the per-Gaussian vote histogram is then exchanged (dist.py, protocol v3)
+            gsx.dist.configure_a2a(ctx, world)
+            lo, hi = gsx.dist.view_range(len(todo), rank, world)
+        else:
+            lo, hi = 0, len(todo)
+        if hi - lo > 255 and world > 1:
+            raise ValueError("at most 255 views per GPU in the multi-GPU exchange")
         ctx.upload_positions(gaussians)
-        ctx.vote_begin(n_classes, 0, max(1, len(todo)))
-        for camera, img_path in todo:
+        ctx.vote_begin(n_classes, lo, max(1, len(todo)))
+        for camera, img_path in todo[lo:hi]:
             print(f"Processing image {os.path.basename(img_path)}...")
             if segmap_dir is not None:
                 seg_map = np.load(os.path.join(segmap_dir, camera["img_name"] + "_segmap.npy"))
             else:
                 seg_map = segment_image(img_path, output_dir, processor, model, device, model_type)
             ctx.vote_view(camera, seg_map, _image_size(img_path))
+        if world > 1:
+            return gsx.dist.exchange_labels_sparse(gsx.dist.GpuSparseShard(ctx))
         return ctx.vote_finalize()
     finally:
         if own:
             ctx.close()
+
+
+def _shutdown():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _world():
+    """(world size, rank) of a torch.distributed run (python -m torch.distributed.run ... this_script.py);
+    initialises the process group on first use.  (1, 0) for a plain single-process run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 1, 0
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("GSX_DIST_BACKEND", "nccl")      # "gloo": functional rehearsal on one GPU
+        local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_world_size(), dist.get_rank()
 
 
 def save_labeled_ply(output_file, plydata, labels):
@@ -167,8 +208,13 @@ def main(argv=None):
     print("Loading gaussians...")
     gaussians, plydata = load_gaussians(args.ply_file)
     print("Assigning labels...")
-    labels = assign_labels(gaussians, cameras, args.input_dir, args.output_dir, model_type=args.model,
-                           segmap_dir=args.segmap_dir, n_classes=args.n_classes)
+    try:
+        labels = assign_labels(gaussians, cameras, args.input_dir, args.output_dir, model_type=args.model,
+                               segmap_dir=args.segmap_dir, n_classes=args.n_classes)
+    finally:
+        _shutdown()
+    if int(os.environ.get("RANK", "0")) != 0:
+        return          # every rank holds the same labels; rank 0 writes the file
     print("Saving labeled PLY file...")
     save_labeled_ply(args.output_file, plydata, labels)
     print(f"Done! Labeled PLY file saved as {args.output_file}")

@@ -57,6 +57,8 @@ typedef enum gsx_seg_dtype {
  * context
  * ------------------------------------------------------------------------------------------- */
 int gsx_abi_version(void);
+/* number of HIP devices visible to this process (0 if none / no driver) */
+int gsx_device_count(void);
 /* device_id: HIP device ordinal of this process's GPU.  Fails (GSX_E_HIP) if the device is
  * missing or is not gfx950. */
 int gsx_create(int device_id, gsx_ctx** out);

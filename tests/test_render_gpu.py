@@ -126,6 +126,13 @@ def test_render_options_do_not_change_the_frame(gsx):
     assert pairs[1] < 0.8 * pairs[0]
 
 
+def test_export_splat_file(ctx, g, tmp_path):
+    ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
+    path = str(tmp_path / "scene.splat")
+    assert ctx.export_splat(path) == len(g["xyz"])
+    assert np.array_equal(np.fromfile(path, np.uint8).reshape(-1, 32), g["buffer"])     # byte-exact vs the viewer's own packer
+
+
 def test_fallbacks_and_empty(ctx):
     W, H = 160, 90
     cam = scene.make_cameras(3, W, H, convention="c2w")[1]
