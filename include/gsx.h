@@ -120,7 +120,7 @@ int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y)
  * flush/finalize time; they stay resident until the next gsx_vote_begin so that a run can be
  * repeated (gsx_vote_rewind) without re-uploading.
  * ------------------------------------------------------------------------------------------- */
-/* n_classes: labels are -1 .. n_classes-1 (n_classes <= 254).
+/* n_classes: labels are -1 .. n_classes-1 (1 <= n_classes <= 255: the on-device maps are u8).
  * first_view / total_views: this ctx will receive the global view indices
  * [first_view, first_view + k); total_views is the number of views over ALL ranks (sizes the
  * counters: <= 65535).  Single GPU: first_view = 0, total_views = number of views (upper bound ok). */

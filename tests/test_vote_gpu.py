@@ -355,7 +355,10 @@ def test_errors(ctx, gsx):
     with pytest.raises(ValueError):
         ctx.vote_view(cam, np.full((48, 64), 9, np.int32))        # more views than announced
     with pytest.raises(gsx.GsxError):
-        ctx.vote_begin(300, 0, 1)                                  # unsupported class count
+        ctx.vote_begin(256, 0, 1)                                  # unsupported class count (u8 maps hold label+1)
+    ctx.vote_begin(255, 0, 1)                                      # the largest supported one
+    ctx.vote_view(cam, np.full((48, 64), 254, np.int32))
+    assert (ctx.vote_finalize() == np.where(oracle.project_many(np.zeros((10, 3), np.float32), cam)[0] >= 0, 254, -1)).all()
 
 
 def test_full_size_properties(ctx):
