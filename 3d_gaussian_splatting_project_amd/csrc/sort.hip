@@ -9,8 +9,10 @@
 //   radix_rowscan  one workgroup per digit: exclusive scan along the tiles, row total -> rowsum
 //   radix_scatter  wave-ballot multi-split: every wave ranks its 64 keys per round with 8
 //                  __ballot()s (peers = lanes holding the same digit), LDS holds the per-wave digit
-//                  counters, the scatter is stable by construction (tile, wave, round, lane order)
-// All loads are coalesced 4 B/lane; the scatter writes runs of equal digits.
+//                  counters (stable by construction: tile, wave, round, lane order); the tile is then
+//                  reordered through LDS so that consecutive lanes store consecutive elements of one
+//                  digit's run
+// All loads are coalesced 4 B/lane; the stores are coalesced runs of equal digits.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -79,8 +81,11 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
                                                                     const uint32_t* __restrict__ hist,
                                                                     const uint32_t* __restrict__ rowsum, int ntiles) {
     __shared__ uint32_t gbase[256];               // global start of this tile's run of each digit
-    __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counters, then exclusive bases
+    __shared__ uint32_t dstart[256];              // start of each digit inside the tile's locally sorted order
+    __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counters, then tile-local exclusive bases
     __shared__ uint32_t wsum[kSortWaves];
+    __shared__ uint32_t sk[kSortTile];            // the tile, locally sorted by digit (stable)
+    __shared__ uint32_t sv[kSortTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = threadIdx.x;
 
@@ -103,15 +108,18 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     }
     __syncthreads();
 
-    const long long wbase_idx = (long long)blockIdx.x * kSortTile + (long long)wave * kWaveChunk;
+    const long long tile_base = (long long)blockIdx.x * kSortTile;
+    const long long wbase_idx = tile_base + (long long)wave * kWaveChunk;
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t key[kSortItems];
+    uint32_t val[kSortItems];
     uint32_t rank[kSortItems];
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const long long i = wbase_idx + r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? keys_in[i] : 0u;
+        val[r] = valid ? vals_in[i] : 0u;
         const uint32_t dg = (key[r] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -126,7 +134,23 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     }
     __syncthreads();
     {
-        uint32_t run = gbase[d];
+        // tile-local exclusive start of digit d (scan over the digits of the tile's totals), then per-wave bases
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) tot += wcount[w][d];
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        __syncthreads();  // wsum is reused
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        uint32_t run = off + inc - tot;
+        dstart[d] = run;
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) {
             const uint32_t c = wcount[w][d];
@@ -135,15 +159,25 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         }
     }
     __syncthreads();
+    // local reorder through LDS, so that the global stores below are coalesced runs of one digit
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const long long i = wbase_idx + r * 64 + lane;
         if (i < n) {
             const uint32_t dg = (key[r] >> shift) & mask;
-            const uint32_t pos = wcount[wave][dg] + rank[r];
-            keys_out[pos] = key[r];
-            vals_out[pos] = vals_in[i];
+            const uint32_t lpos = wcount[wave][dg] + rank[r];
+            sk[lpos] = key[r];
+            sv[lpos] = val[r];
         }
+    }
+    __syncthreads();
+    const int count = (int)min((long long)kSortTile, n - tile_base);
+    for (int j = threadIdx.x; j < count; j += kSortBlock) {
+        const uint32_t k = sk[j];
+        const uint32_t dg = (k >> shift) & mask;
+        const uint32_t pos = gbase[dg] + ((uint32_t)j - dstart[dg]);
+        keys_out[pos] = k;
+        vals_out[pos] = sv[j];
     }
 }
 
