@@ -490,6 +490,11 @@ __global__ __launch_bounds__(kRB) void gather_count_kernel(const uint32_t* __res
     if (j < n) out[j] = tile_count[by_depth[j]];
 }
 
+// Wave-cooperative emission.  The 64 splats of a wave own one contiguous stretch of the pair arrays
+// (their offsets are an exclusive scan in depth order), so the lanes write that stretch element by element:
+// a lane finds the splat owning its element by a binary search over the wave's offsets (shuffles) and
+// derives the tile from the element's rank inside the splat's rectangle.  Stores are coalesced and a splat
+// covering 4000 tiles no longer serialises one lane.
 __global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* __restrict__ by_depth,
                                                     const uint32_t* __restrict__ tile_rect,
                                                     const uint32_t* __restrict__ count_sorted,
@@ -498,26 +503,66 @@ __global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* 
                                                     int exact_cull, uint32_t* __restrict__ keys,
                                                     uint32_t* __restrict__ vals) {
     const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (j >= n || count_sorted[j] == 0) return;
-    const uint32_t i = by_depth[j];
-    const uint32_t rect = tile_rect[i];
-    const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
-    uint32_t o = offset[j];
-    const uint32_t o_end = o + count_sorted[j];  // never write past this splat's share
-    const bool cull = exact_cull && (tx1 > tx0 || ty1 > ty0);  // must mirror preprocess_kernel's count exactly
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    if (cull) {
-        r0 = rec0[i];
-        r1 = rec1[i];
-    }
-    for (uint32_t ty = ty0; ty <= ty1; ++ty)
-        for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-            if (cull && !tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, H, tx, ty)) continue;
-            if (o >= o_end) return;
-            keys[o] = ty * (uint32_t)tiles_x + tx;
-            vals[o] = i;
-            ++o;
+    const int lane = threadIdx.x & 63;
+    const bool live = j < n;
+    const uint32_t cnt = live ? count_sorted[j] : 0u;
+    if (exact_cull) {
+        // culled binning keeps the per-splat loop: the kept tiles are not a dense rectangle
+        if (cnt == 0) return;
+        const uint32_t i = by_depth[j];
+        const uint32_t rect = tile_rect[i];
+        const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
+        uint32_t o = offset[j];
+        const uint32_t o_end = o + cnt;  // never write past this splat's share
+        const bool cull = tx1 > tx0 || ty1 > ty0;  // must mirror preprocess_kernel's count exactly
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        if (cull) {
+            r0 = rec0[i];
+            r1 = rec1[i];
         }
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                if (cull && !tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, H, tx, ty)) continue;
+                if (o >= o_end) return;
+                keys[o] = ty * (uint32_t)tiles_x + tx;
+                vals[o] = i;
+                ++o;
+            }
+        return;
+    }
+    const uint32_t off = live ? offset[j] : 0u;
+    const uint32_t i = (live && cnt) ? by_depth[j] : 0u;
+    const uint32_t rect = (live && cnt) ? tile_rect[i] : 0u;
+    // wave totals: first offset and number of pairs of the wave's stretch
+    uint32_t total = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+    if (total == 0) return;
+    // start of the stretch = offset of the first live lane (offsets are non-decreasing with the lane)
+    const uint32_t start = __shfl(off, 0);
+    // the search key: offsets are non-decreasing over the lanes; a splat without tiles shares its offset with the
+    // next splat that has some, and that one is the LAST lane holding the value; lanes past n carry the end
+    const uint32_t my_off = live ? off : start + total;
+    for (uint32_t e = (uint32_t)lane; e < total; e += 64u) {
+        const uint32_t target = start + e;
+        int lo = 0, hi = 63;  // largest lane s with my_off[s] <= target
+#pragma unroll
+        for (int step = 0; step < 6; ++step) {
+            const int mid = (lo + hi + 1) >> 1;
+            const uint32_t om = __shfl(my_off, mid);
+            if (om <= target) lo = mid;
+            else hi = mid - 1;
+        }
+        const uint32_t s_off = __shfl(my_off, lo);
+        const uint32_t s_rect = __shfl(rect, lo);
+        const uint32_t s_i = __shfl(i, lo);
+        const uint32_t tx0 = s_rect & 255u, tx1 = (s_rect >> 8) & 255u, ty0 = (s_rect >> 16) & 255u;
+        const uint32_t w = tx1 - tx0 + 1u;
+        const uint32_t local = target - s_off;
+        const uint32_t ry = local / w, rx = local - ry * w;
+        keys[target] = (ty0 + ry) * (uint32_t)tiles_x + (tx0 + rx);
+        vals[target] = s_i;
+    }
 }
 
 __global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, long long P,
