@@ -543,8 +543,11 @@ __global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* 
     // the search key: offsets are non-decreasing over the lanes; a splat without tiles shares its offset with the
     // next splat that has some, and that one is the LAST lane holding the value; lanes past n carry the end
     const uint32_t my_off = live ? off : start + total;
-    for (uint32_t e = (uint32_t)lane; e < total; e += 64u) {
-        const uint32_t target = start + e;
+    // every lane runs every iteration: the shuffles below read registers of ALL lanes (a lane that had left the
+    // loop would hand out zeros); only the stores are predicated
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t e = base + (uint32_t)lane;
+        const uint32_t target = start + min(e, total - 1u);
         int lo = 0, hi = 63;  // largest lane s with my_off[s] <= target
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
@@ -560,16 +563,19 @@ __global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* 
         const uint32_t w = tx1 - tx0 + 1u;
         const uint32_t local = target - s_off;
         const uint32_t ry = local / w, rx = local - ry * w;
-        keys[target] = (ty0 + ry) * (uint32_t)tiles_x + (tx0 + rx);
-        vals[target] = s_i;
+        if (e < total) {
+            keys[target] = (ty0 + ry) * (uint32_t)tiles_x + (tx0 + rx);
+            vals[target] = s_i;
+        }
     }
 }
 
-__global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, long long P,
+__global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, long long P, int ntiles,
                                                       int2* __restrict__ ranges) {
     const long long p = (long long)blockIdx.x * kRB + threadIdx.x;
     if (p >= P) return;
     const uint32_t t = keys[p];
+    if (t >= (uint32_t)ntiles) return;  // defensive: a key outside the frame must never index the table
     if (p == 0 || keys[p - 1] != t) ranges[t].x = (int)p;
     if (p == P - 1 || keys[p + 1] != t) ranges[t].y = (int)(p + 1);
 }
@@ -819,7 +825,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             {
                 ProfScope ps(c, "render_ranges");
                 hipLaunchKernelGGL(ranges_kernel, dim3(grid_for(P)), dim3(kRB), 0, c->stream,
-                                   where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), (long long)P,
+                                   where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), (long long)P, ntiles,
                                    c->r_ranges.as<int2>());
             }
             GSX_HIP(c, hipGetLastError());
