@@ -106,6 +106,91 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
 }
 
+// ---- two pixels per thread ---------------------------------------------------------------------------------
+// Same maths, but a thread owns the pixels (x, y) and (x, y + 8) of the tile and carries them as 2-vectors:
+// hipcc turns the element-wise products and sums into v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two fp32
+// results per lane and instruction) without the operand shuffles the one-pixel kernel needs, and a tile is
+// 2 waves instead of 4, so every staged record is read from LDS half as often.  Per component the operation
+// order is unchanged (mul, mul, add; no contraction), so `discard` decides exactly as before.
+typedef float f2 __attribute__((ext_vector_type(2)));
+static constexpr int kBlend2Threads = 128;
+static constexpr int kBlend2Chunk = 256;
+
+struct Accum2 {
+    f2 r, g, b, a;
+};
+
+__device__ __forceinline__ void blend_one2(Accum2& acc, float fxp, f2 fyp, const float4 r0, const float4 r1,
+                                           const float2 r2) {
+    const float dx = fxp - r0.x;
+    const f2 dy = fyp - r0.y;
+    const f2 vx = dx * r0.z + dy * r0.w;
+    const f2 vy = dx * r1.x + dy * r1.y;
+    const f2 q = vx * vx + vy * vy;  // A = -q; `if (A < -4.0) discard;` <=> q > 4 (negation is exact)
+    const bool k0 = !(q.x > 4.0f), k1 = !(q.y > 4.0f);
+    if (k0 | k1) {
+        f2 B;
+        B.x = k0 ? __expf(-q.x) * r2.y : 0.0f;  // a discarded fragment adds exactly nothing: fma(om, 0, x) == x
+        B.y = k1 ? __expf(-q.y) * r2.y : 0.0f;
+        const f2 om = 1.0f - acc.a;  // ONE_MINUS_DST_ALPHA, ONE
+        acc.r = __builtin_elementwise_fma(om, B * r1.z, acc.r);
+        acc.g = __builtin_elementwise_fma(om, B * r1.w, acc.g);
+        acc.b = __builtin_elementwise_fma(om, B * r2.x, acc.b);
+        acc.a = __builtin_elementwise_fma(om, B, acc.a);
+    }
+}
+
+__global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __restrict__ ranges,
+                                                                const uint32_t* __restrict__ tile_order,
+                                                                const uint32_t* __restrict__ vals,
+                                                                const float4* __restrict__ rec0,
+                                                                const float4* __restrict__ rec1,
+                                                                const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                                const int* __restrict__ dropped, long long n,
+                                                                unsigned long long* __restrict__ consumed,
+                                                                float4* __restrict__ image) {
+    __shared__ float4 s0[kBlend2Chunk];
+    __shared__ float4 s1[kBlend2Chunk];
+    __shared__ float2 s2[kBlend2Chunk];
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (threadIdx.x & (kTile - 1));
+    const int py0 = ty * kTile + (threadIdx.x >> 4), py1 = py0 + 8;
+    const bool in0 = px < W && py0 < H, in1 = px < W && py1 < H;
+    const float fxp = (float)px + 0.5f;
+    f2 fyp;
+    fyp.x = (float)H - ((float)py0 + 0.5f);
+    fyp.y = (float)H - ((float)py1 + 0.5f);
+    Accum2 acc{};
+    const int2 range = ranges[tile];
+    int staged = 0;
+    for (int base = range.x; base < range.y; base += kBlend2Chunk) {
+        const int cnt = min(kBlend2Chunk, range.y - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += kBlend2Threads) {
+            const uint32_t id = vals[base + t];
+            s0[t] = rec0[id];
+            s1[t] = rec1[id];
+            s2[t] = rec2[id];
+        }
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) blend_one2(acc, fxp, fyp, s0[k], s1[k], s2[k]);
+        staged += cnt;
+        const bool done0 = !in0 || acc.a.x > 1.0f - 1.0e-5f, done1 = !in1 || acc.a.y > 1.0f - 1.0e-5f;
+        if (__syncthreads_and(done0 && done1)) break;
+    }
+    const int nd = n > 0 ? *dropped : 0;
+    if (nd > 0) {
+        const float4 r0 = rec0[0];
+        const float4 r1 = rec1[0];
+        const float2 r2 = rec2[0];
+        for (int k = 0; k < nd; ++k) blend_one2(acc, fxp, fyp, r0, r1, r2);
+    }
+    if (in0) image[(size_t)py0 * W + px] = make_float4(acc.r.x, acc.g.x, acc.b.x, acc.a.x);
+    if (in1) image[(size_t)py1 * W + px] = make_float4(acc.r.y, acc.g.y, acc.b.y, acc.a.y);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
+}
+
 int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
                  unsigned long long* consumed_dev) {
     const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
@@ -123,6 +208,13 @@ int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* drop
         order = where ? v1 : v0;
     }
     ProfScope ps(c, "render_blend");
+    if (c->opt_blend_pk2) {
+        hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
+                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           (long long)c->rn, consumed_dev, c->r_image.as<float4>());
+        GSX_HIP(c, hipGetLastError());
+        return GSX_OK;
+    }
     hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                        c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
                        (long long)c->rn, consumed_dev, c->r_image.as<float4>());

@@ -78,6 +78,7 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
  *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
+ *   "blend_pk2"    (default 1)  rasterizer: blend two pixels per thread with packed fp32 instructions
  *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
  *                               (minimum of the quadratic over the tile), not its whole bounding box.  Measured
  *                               on the 3 M-splat scene: pairs -23 %, sort -0.2 ms, but the per-splat tile loops
