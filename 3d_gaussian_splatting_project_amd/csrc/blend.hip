@@ -120,13 +120,15 @@ struct Accum2 {
     f2 r, g, b, a;
 };
 
-__device__ __forceinline__ void blend_one2(Accum2& acc, float fxp, f2 fyp, const float4 r0, const float4 r1,
-                                           const float2 r2) {
+__device__ __forceinline__ f2 splat_q2(float fxp, f2 fyp, const float4 r0, const float4 r1) {
     const float dx = fxp - r0.x;
     const f2 dy = fyp - r0.y;
     const f2 vx = dx * r0.z + dy * r0.w;
     const f2 vy = dx * r1.x + dy * r1.y;
-    const f2 q = vx * vx + vy * vy;  // A = -q; `if (A < -4.0) discard;` <=> q > 4 (negation is exact)
+    return vx * vx + vy * vy;  // A = -q; `if (A < -4.0) discard;` <=> q > 4 (negation is exact)
+}
+
+__device__ __forceinline__ void accumulate2(Accum2& acc, f2 q, const float4 r1, const float2 r2) {
     const bool k0 = !(q.x > 4.0f), k1 = !(q.y > 4.0f);
     if (k0 | k1) {
         f2 B;
@@ -138,6 +140,11 @@ __device__ __forceinline__ void blend_one2(Accum2& acc, float fxp, f2 fyp, const
         acc.b = __builtin_elementwise_fma(om, B * r2.x, acc.b);
         acc.a = __builtin_elementwise_fma(om, B, acc.a);
     }
+}
+
+__device__ __forceinline__ void blend_one2(Accum2& acc, float fxp, f2 fyp, const float4 r0, const float4 r1,
+                                           const float2 r2) {
+    accumulate2(acc, splat_q2(fxp, fyp, r0, r1), r1, r2);
 }
 
 __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __restrict__ ranges,
@@ -174,7 +181,17 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
             s2[t] = rec2[id];
         }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) blend_one2(acc, fxp, fyp, s0[k], s1[k], s2[k]);
+        // the splats are independent up to the accumulation: evaluate 4 quadratics at once (4 dependency chains
+        // in flight - the long tiles run one or two waves per CU, latency is what they wait for), then blend in order
+        int k = 0;
+        for (; k + 4 <= cnt; k += 4) {
+            f2 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = splat_q2(fxp, fyp, s0[k + u], s1[k + u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accumulate2(acc, q[u], s1[k + u], s2[k + u]);
+        }
+        for (; k < cnt; ++k) blend_one2(acc, fxp, fyp, s0[k], s1[k], s2[k]);
         staged += cnt;
         const bool done0 = !in0 || acc.a.x > 1.0f - 1.0e-5f, done1 = !in1 || acc.a.y > 1.0f - 1.0e-5f;
         if (__syncthreads_and(done0 && done1)) break;
