@@ -148,9 +148,12 @@ def main():
     ctx.vote_begin(args.classes, first, total_views)
     host_segs = []
     keep_host = rank == 0 and world == 1 and args.cpu_sample > 0
+    ingest_s = 0.0
     for v in range(V):
         seg = scene.make_segmap(H, W, args.classes, 3000 + first + v)
-        ctx.vote_view(cams_all[first + v], seg)
+        t1 = time.perf_counter()
+        ctx.vote_view(cams_all[first + v], seg)          # host int32 map -> PCIe -> u8 tiles in HBM (synchronous)
+        ingest_s += time.perf_counter() - t1
         if keep_host:
             host_segs.append(seg)
     ctx.synchronize()
@@ -275,7 +278,9 @@ def main():
                                                             "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"),
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
-                       "setup_seconds": round(setup_s, 1)},
+                       "setup_seconds": round(setup_s, 1),
+                       "host_map_ingest_ms_per_view": round(ingest_s / max(1, V) * 1e3, 3),
+                       "pcie_inclusive_value": round(n * total_views / (ingest_s + elapsed / args.steps), 1) if world == 1 else None},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "render": render,
