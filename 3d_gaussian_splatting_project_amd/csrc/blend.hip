@@ -208,6 +208,91 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
 }
 
+// ---- four pixels per thread, one wave per tile ----------------------------------------------------------------
+// A tile that never saturates walks its whole list one dependent splat after the other; what it waits for is
+// latency.  Here a lane owns FOUR pixels (rows y, y+4, y+8, y+12 as two packed pairs): four independent
+// accumulation chains per lane hide that latency, the whole tile is one wave (no barrier partner to wait
+// for), and every staged record is read from LDS once per tile.
+static constexpr int kBlend4Threads = 64;
+static constexpr int kBlend4Chunk = 128;
+
+__global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __restrict__ ranges,
+                                                                const uint32_t* __restrict__ tile_order,
+                                                                const uint32_t* __restrict__ vals,
+                                                                const float4* __restrict__ rec0,
+                                                                const float4* __restrict__ rec1,
+                                                                const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                                const int* __restrict__ dropped, long long n,
+                                                                unsigned long long* __restrict__ consumed,
+                                                                float4* __restrict__ image) {
+    __shared__ float4 s0[kBlend4Chunk];
+    __shared__ float4 s1[kBlend4Chunk];
+    __shared__ float2 s2[kBlend4Chunk];
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * kTile + (threadIdx.x & (kTile - 1));
+    const int row = ty * kTile + (threadIdx.x >> 4);  // rows row, row+4, row+8, row+12
+    const float fxp = (float)px + 0.5f;
+    f2 fyA, fyB;
+    fyA.x = (float)H - ((float)row + 0.5f);
+    fyA.y = (float)H - ((float)(row + 8) + 0.5f);
+    fyB.x = (float)H - ((float)(row + 4) + 0.5f);
+    fyB.y = (float)H - ((float)(row + 12) + 0.5f);
+    const bool in[4] = {px < W && row < H, px < W && row + 8 < H, px < W && row + 4 < H, px < W && row + 12 < H};
+    Accum2 accA{}, accB{};
+    const int2 range = ranges[tile];
+    int staged = 0;
+    for (int base = range.x; base < range.y; base += kBlend4Chunk) {
+        const int cnt = min(kBlend4Chunk, range.y - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += kBlend4Threads) {
+            const uint32_t id = vals[base + t];
+            s0[t] = rec0[id];
+            s1[t] = rec1[id];
+            s2[t] = rec2[id];
+        }
+        __syncthreads();
+        int k = 0;
+        for (; k + 2 <= cnt; k += 2) {
+            f2 qA[2], qB[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                qA[u] = splat_q2(fxp, fyA, s0[k + u], s1[k + u]);
+                qB[u] = splat_q2(fxp, fyB, s0[k + u], s1[k + u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                accumulate2(accA, qA[u], s1[k + u], s2[k + u]);
+                accumulate2(accB, qB[u], s1[k + u], s2[k + u]);
+            }
+        }
+        for (; k < cnt; ++k) {
+            blend_one2(accA, fxp, fyA, s0[k], s1[k], s2[k]);
+            blend_one2(accB, fxp, fyB, s0[k], s1[k], s2[k]);
+        }
+        staged += cnt;
+        const float lim = 1.0f - 1.0e-5f;
+        const bool done = (!in[0] || accA.a.x > lim) && (!in[1] || accA.a.y > lim) && (!in[2] || accB.a.x > lim) &&
+                          (!in[3] || accB.a.y > lim);
+        if (__syncthreads_and(done)) break;
+    }
+    const int nd = n > 0 ? *dropped : 0;
+    if (nd > 0) {
+        const float4 r0 = rec0[0];
+        const float4 r1 = rec1[0];
+        const float2 r2 = rec2[0];
+        for (int k = 0; k < nd; ++k) {
+            blend_one2(accA, fxp, fyA, r0, r1, r2);
+            blend_one2(accB, fxp, fyB, r0, r1, r2);
+        }
+    }
+    if (in[0]) image[(size_t)row * W + px] = make_float4(accA.r.x, accA.g.x, accA.b.x, accA.a.x);
+    if (in[1]) image[(size_t)(row + 8) * W + px] = make_float4(accA.r.y, accA.g.y, accA.b.y, accA.a.y);
+    if (in[2]) image[(size_t)(row + 4) * W + px] = make_float4(accB.r.x, accB.g.x, accB.b.x, accB.a.x);
+    if (in[3]) image[(size_t)(row + 12) * W + px] = make_float4(accB.r.y, accB.g.y, accB.b.y, accB.a.y);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
+}
+
 int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
                  unsigned long long* consumed_dev) {
     const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
@@ -225,6 +310,13 @@ int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* drop
         order = where ? v1 : v0;
     }
     ProfScope ps(c, "render_blend");
+    if (c->opt_blend_pk2 == 2) {
+        hipLaunchKernelGGL(blend4_kernel, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
+                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           (long long)c->rn, consumed_dev, c->r_image.as<float4>());
+        GSX_HIP(c, hipGetLastError());
+        return GSX_OK;
+    }
     if (c->opt_blend_pk2) {
         hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,

@@ -151,7 +151,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "seg_tiled") c->opt_seg_tiled = value != 0;
     else if (k == "tile_lpt") c->opt_tile_lpt = value != 0;
     else if (k == "exact_cull") c->opt_exact_cull = value != 0;
-    else if (k == "blend_pk2") c->opt_blend_pk2 = value != 0;
+    else if (k == "blend_pk2") c->opt_blend_pk2 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "exchange_slabs") {
         if (value < 1 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: exchange_slabs must be in [1,64]");
         c->opt_slabs = (int)value;

@@ -112,7 +112,7 @@ def test_render_options_do_not_change_the_frame(gsx):
     a["scale"][:, 0] += np.float32(np.log(6.0))           # elongated splats: the bounding box is mostly empty
     cam = scene.make_cameras(5, W, H, convention="c2w")[1]
     frames, pairs = [], []
-    for opts in ({"exact_cull": 0, "tile_lpt": 0, "blend_pk2": 0}, {"exact_cull": 1, "tile_lpt": 0}, {"exact_cull": 1, "tile_lpt": 1}):
+    for opts in ({"exact_cull": 0, "tile_lpt": 0, "blend_pk2": 0}, {"exact_cull": 1, "tile_lpt": 0, "blend_pk2": 2}, {"exact_cull": 1, "tile_lpt": 1, "blend_pk2": 2}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
