@@ -156,7 +156,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         if (value < 1 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: exchange_slabs must be in [1,64]");
         c->opt_slabs = (int)value;
     } else if (k == "exchange_local") c->opt_local_codes = value != 0;
-    else if (k == "shared_rcp") c->opt_shared_rcp = value != 0;
+    else if (k == "fast_div") c->opt_fast_div = value != 0;
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)

@@ -75,6 +75,7 @@ struct alignas(16) ViewDesc {
     int seg_w;
     int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
     int seg_tw;      // 16x8 tiles per map row (0: row-major map)
+    int cam_w, cam_h;  // camera width / height as integers (visibility test of the certified path)
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
     int seg_h;
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
@@ -109,7 +110,7 @@ struct Ctx {
     int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %, net slower)
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
-    int opt_shared_rcp = 0;    // one reciprocal chain for the two IEEE divisions of a projection (measured 2 % slower)
+    int opt_fast_div = 1;      // certified single-reciprocal projection with exact fallback (vote.hip project<>)
 
     // vote
     bool vote_begun = false;

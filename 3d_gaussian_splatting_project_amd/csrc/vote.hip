@@ -50,7 +50,7 @@ static constexpr int kMaxBatch = 255;  // views per fused launch: LDS counters a
 struct ViewRegs {
     double R[9], t[3], fx, fy, half_w, half_h, width, height;
     long long seg_off;
-    int seg_w, unit_scale, seg_tw;
+    int seg_w, unit_scale, seg_tw, cam_w, cam_h;
 };
 
 __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
@@ -69,10 +69,12 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
     r.seg_w = vp->seg_w;
     r.unit_scale = vp->unit_scale;
     r.seg_tw = vp->seg_tw;
+    r.cam_w = vp->cam_w;
+    r.cam_h = vp->cam_h;
     asm volatile("" : "+s"(r.R[0]), "+s"(r.R[1]), "+s"(r.R[2]), "+s"(r.R[3]), "+s"(r.R[4]), "+s"(r.R[5]), "+s"(r.R[6]),
                       "+s"(r.R[7]), "+s"(r.R[8]), "+s"(r.t[0]), "+s"(r.t[1]), "+s"(r.t[2]), "+s"(r.fx), "+s"(r.fy),
                       "+s"(r.half_w), "+s"(r.half_h), "+s"(r.width), "+s"(r.height), "+s"(r.seg_off), "+s"(r.seg_w),
-                      "+s"(r.unit_scale), "+s"(r.seg_tw));
+                      "+s"(r.unit_scale), "+s"(r.seg_tw), "+s"(r.cam_w), "+s"(r.cam_h));
     return r;
 }
 
@@ -81,57 +83,53 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
     return __builtin_fma(Rr[2], v2, __builtin_fma(Rr[0], v0, Rr[1] * v1));
 }
 
-// Two IEEE-754 divisions by the same denominator, bit-identical to `ax / b` and `ay / b`.
-// hipcc expands an fp64 division into div_scale(den), rcp, two Newton steps, div_scale(num), mul, fma,
-// div_fmas, div_fixup.  Everything up to the refined reciprocal depends only on the SCALED denominator,
-// which is the same for both quotients unless v_div_scale rescales for an extreme exponent gap; so the
-// reciprocal chain (1 v_rcp_f64 + 4 v_fma_f64) is computed once.  A lane whose two scaled denominators
-// differ takes the plain division (never seen on real data; covered by the edge-case tests).
-__device__ __forceinline__ void div2_shared(double ax, double ay, double b, double& qx, double& qy) {
-    bool unused, vx, vy;
-    const double sdx = __builtin_amdgcn_div_scale(ax, b, false, &unused);
-    const double sdy = __builtin_amdgcn_div_scale(ay, b, false, &unused);
-    const double nsd = -sdx;
-    double r = __builtin_amdgcn_rcp(sdx);
-    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
-    const double snx = __builtin_amdgcn_div_scale(ax, b, true, &vx);
-    const double mx = snx * r;
-    qx = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, mx, snx), r, mx, vx), b, ax);
-    const double sny = __builtin_amdgcn_div_scale(ay, b, true, &vy);
-    const double my = sny * r;
-    qy = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, my, sny), r, my, vy), b, ay);
-    if (__double_as_longlong(sdx) != __double_as_longlong(sdy)) qy = ay / b;
-}
+// project_gaussian (dls.py:43-82).  Returns false where the reference returns None (:72-73, :80-82).
+//
+// DIV == kDivExact: the two IEEE-754 divisions of dls.py:76-77, operation for operation.
+// DIV == kDivCertified: the same results from ONE reciprocal.  r ~ 1/pc2 (v_rcp_f64 + two Newton steps,
+//   relative error <= 2^-48), s^ = (f*pc)*r + half is within 2^-30 of the reference's px = fl(fl(f*pc/pc2) + half)
+//   whenever |px| <= 2^18, and far outside the frame (<= 2^16 pixels) otherwise.  If s^ is at least 2^-20 away
+//   from every integer, floor(px) == floor(s^) is CERTAIN, and so are `0 <= px < width` (integer width) and the
+//   truncation int(px).  A lane that is closer than that to an integer (~4e-6 of them), or whose arithmetic left
+//   the finite range, falls through to the exact divisions.  11 fewer fp64 instructions per visible pair.
+enum { kDivExact = 0, kDivCertified = 1 };
 
-// returns false where the reference returns None (dls.py:72-73, 80-82)
-template <bool SHARED_RCP>
+template <int DIV>
 __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
     if (!(pc2 > 0.0)) return false;  // `pc2 <= 0` -> None; a NaN depth fails the bounds test below anyway
     const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
     const double pc1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
-    double qx, qy;
-    if (SHARED_RCP) {
-        div2_shared(vd.fx * pc0, vd.fy * pc1, pc2, qx, qy);
-    } else {
-        qx = (vd.fx * pc0) / pc2;
-        qy = (vd.fy * pc1) / pc2;
+    const double ax = vd.fx * pc0, ay = vd.fy * pc1;
+    if (DIV == kDivCertified) {
+        double r = __builtin_amdgcn_rcp(pc2);
+        r = __builtin_fma(__builtin_fma(-pc2, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-pc2, r, 1.0), r, r);
+        const double sx = ax * r + vd.half_w, sy = ay * r + vd.half_h;
+        const double flx = floor(sx), fly = floor(sy);
+        const double frx = sx - flx, fry = sy - fly;
+        const double lo = 9.5367431640625e-07, hi = 1.0 - 9.5367431640625e-07;  // 2^-20
+        if ((frx >= lo) & (frx <= hi) & (fry >= lo) & (fry <= hi)) {  // false for NaN / infinity
+            const int kx = (int)flx, ky = (int)fly;                    // saturating conversions
+            if (((unsigned)kx >= (unsigned)vd.cam_w) | ((unsigned)ky >= (unsigned)vd.cam_h)) return false;
+            xi = kx;
+            yi = ky;
+            return true;
+        }
     }
-    const double px = qx + vd.half_w;  // dls.py:76
-    const double py = qy + vd.half_h;  // dls.py:77
+    const double px = ax / pc2 + vd.half_w;  // dls.py:76
+    const double py = ay / pc2 + vd.half_h;  // dls.py:77
     if (!((0.0 <= px) && (px < vd.width) && (0.0 <= py) && (py < vd.height))) return false;  // :80
     xi = (int)px;  // int() truncation, :81
     yi = (int)py;
     return true;
 }
 
-// byte offset of the voted pixel inside the seg pool, or -1 (dls.py:276-288)
-template <bool SHARED_RCP>
+template <int DIV>
 __device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, double X, double Y, double Z) {
     const ViewRegs vd = load_view(vp);
     int xi, yi;
-    if (!project<SHARED_RCP>(vd, X, Y, Z, xi, yi)) return -1;
+    if (!project<DIV>(vd, X, Y, Z, xi, yi)) return -1;
     if (!vd.unit_scale) {
         const double xs = trunc((double)xi * vp->wscale);  // :281
         const double ys = trunc((double)yi * vp->hscale);  // :282
@@ -144,7 +142,7 @@ __device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, 
     return vd.seg_off + (long long)yi * vd.seg_w + xi;
 }
 
-template <bool SHARED_RCP>
+template <int DIV>
 __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                          const float* __restrict__ z, long long n,
                                                          const ViewDesc* __restrict__ vd,
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict
     if (i >= n) return;
     int xi, yi;
     const ViewRegs vr = load_view(vd);
-    const bool vis = project<SHARED_RCP>(vr, (double)x[i], (double)y[i], (double)z[i], xi, yi);
+    const bool vis = project<DIV>(vr, (double)x[i], (double)y[i], (double)z[i], xi, yi);
     const long long o = perm ? (long long)perm[i] : i;  // back to the caller's order
     ox[o] = vis ? xi : -1;
     oy[o] = vis ? yi : -1;
@@ -220,7 +218,7 @@ struct FusedParams {
     const uint32_t* perm;  // sorted slot -> caller's index, or nullptr
 };
 
-template <int U, bool SHARED_RCP, bool LDS_BATCH>
+template <int U, int DIV, bool LDS_BATCH>
 __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
@@ -245,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {  // wave-uniform
-                const long long off = seg_index<SHARED_RCP>(views + v, X, Y, Z);
+                const long long off = seg_index<DIV>(views + v, X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -293,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 // but the only output is this rank's COUNT plane, u8 [slab][bins][sn].  No first-view plane: ties are
 // resolved later, for the tied Gaussians only, by vote_tie_kernel.
 // -------------------------------------------------------------------------------------------------
-template <int U>
+template <int U, int DIV>
 __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    uint8_t* __restrict__ cnt, long long sn) {
     extern __shared__ uint32_t lds[];
@@ -313,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {
-                const long long off = seg_index<false>(views + v, X, Y, Z);
+                const long long off = seg_index<DIV>(views + v, X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void vote_tie_kernel(FusedParams p, const V
     if (pop >= 2) {
         const double X = (double)p.x[i], Y = (double)p.y[i], Z = (double)p.z[i];
         for (int v = 0; v < p.nviews; ++v) {
-            const long long off = seg_index<false>(views + v, X, Y, Z);
+            const long long off = seg_index<kDivCertified>(views + v, X, Y, Z);
             if (off < 0) continue;
             const unsigned b = p.pool[off];
             uint32_t word = 0;
@@ -451,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void vote_tie_resolve_kernel(const uint16_t
 // LDS word per bin: count << 8 | local index of the earliest view that voted it.
 // fv code = FVMAX - global view index of the first vote (larger = earlier; 0 = no vote).
 // -------------------------------------------------------------------------------------------------
-template <int U, typename PT, bool SHARED_RCP>
+template <int U, typename PT, int DIV>
 __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    PT* __restrict__ cnt,
                                                                    PT* __restrict__ fv, long long sn,
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
             const int v = vb - 1 - u;
             bin[u] = -1;
             if (v >= 0) {
-                const long long off = seg_index<SHARED_RCP>(views + v, X, Y, Z);
+                const long long off = seg_index<DIV>(views + v, X, Y, Z);
                 if (off >= 0) bin[u] = pool[off];
             }
         }
@@ -634,6 +632,8 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.half_h = (double)cam->height / 2.0;
     vd.width = (double)cam->width;
     vd.height = (double)cam->height;
+    vd.cam_w = cam->width;
+    vd.cam_h = cam->height;
     vd.wscale = (double)seg_w / (double)img_w;
     vd.hscale = (double)seg_h / (double)img_h;
     vd.seg_w = seg_w;
@@ -658,11 +658,11 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
-        if (c->opt_shared_rcp)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+        if (c->opt_fast_div)
+            hipLaunchKernelGGL(project_kernel<kDivCertified>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
                                dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+            hipLaunchKernelGGL(project_kernel<kDivExact>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
                                dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         e = hipGetLastError();
     }
@@ -891,12 +891,12 @@ int vote_flush(Ctx* c) {
         const int fresh = (c->planes_zero || c->planes_stale) ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
-            auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint16_t, true> : vote_fused_planes_kernel<kUnroll, uint16_t, false>;
+            auto k = c->opt_fast_div ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint16_t>(),
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
-            auto k = c->opt_shared_rcp ? vote_fused_planes_kernel<kUnroll, uint8_t, true> : vote_fused_planes_kernel<kUnroll, uint8_t, false>;
+            auto k = c->opt_fast_div ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
                                c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
@@ -977,17 +977,17 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
             p.stride_dw = odd_dwords(c->bins);
             const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-            // kernel variants: unroll U in {2,4,8} x shared reciprocal x batched LDS reads
+            // kernel variants: unroll U in {2,4,8} x division mode x batched LDS reads
             using K = void (*)(FusedParams, const ViewDesc*, int*);
             const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
             static const K table[3][2][2] = {
-                {{vote_fused_labels_kernel<2, false, false>, vote_fused_labels_kernel<2, false, true>},
-                 {vote_fused_labels_kernel<2, true, false>, vote_fused_labels_kernel<2, true, true>}},
-                {{vote_fused_labels_kernel<4, false, false>, vote_fused_labels_kernel<4, false, true>},
-                 {vote_fused_labels_kernel<4, true, false>, vote_fused_labels_kernel<4, true, true>}},
-                {{vote_fused_labels_kernel<8, false, false>, vote_fused_labels_kernel<8, false, true>},
-                 {vote_fused_labels_kernel<8, true, false>, vote_fused_labels_kernel<8, true, true>}}};
-            K k = table[ui][c->opt_shared_rcp ? 1 : 0][c->opt_lds_batch ? 1 : 0];
+                {{vote_fused_labels_kernel<2, kDivExact, false>, vote_fused_labels_kernel<2, kDivExact, true>},
+                 {vote_fused_labels_kernel<2, kDivCertified, false>, vote_fused_labels_kernel<2, kDivCertified, true>}},
+                {{vote_fused_labels_kernel<4, kDivExact, false>, vote_fused_labels_kernel<4, kDivExact, true>},
+                 {vote_fused_labels_kernel<4, kDivCertified, false>, vote_fused_labels_kernel<4, kDivCertified, true>}},
+                {{vote_fused_labels_kernel<8, kDivExact, false>, vote_fused_labels_kernel<8, kDivExact, true>},
+                 {vote_fused_labels_kernel<8, kDivCertified, false>, vote_fused_labels_kernel<8, kDivCertified, true>}}};
+            K k = table[ui][c->opt_fast_div ? 1 : 0][c->opt_lds_batch ? 1 : 0];
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());
@@ -1031,7 +1031,7 @@ int vote_flush_counts(Ctx* c) {
     if (c->n > 0) {
         FusedParams p = fused_params(c, 1);
         const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-        auto k = vote_fused_counts_kernel<kUnroll>;
+        auto k = c->opt_fast_div ? vote_fused_counts_kernel<kUnroll, kDivCertified> : vote_fused_counts_kernel<kUnroll, kDivExact>;
         if ((rc = set_lds(c, k, lds))) return rc;
         ProfScope ps(c, "vote_fused_counts");
         hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),

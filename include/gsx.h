@@ -75,10 +75,10 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 2, 4, 8
  *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
  *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
- *   "shared_rcp"   (default 0)  the two IEEE divisions of a projection share one reciprocal chain
- *                               (bit-identical; measured ~2 % slower on MI355X, kept as an experiment)
+ *   "fast_div"     (default 1)  projection through ONE reciprocal with a certified margin; lanes within 2^-20 of a
+ *                               pixel boundary (and any non-finite case) take the exact IEEE divisions
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
- *   "blend_pk2"    (default 1)  rasterizer: blend two pixels per thread with packed fp32 instructions
+ *   "blend_pk2"    (default 1)  rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four (one wave per tile)
  *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
  *                               (minimum of the quadratic over the tile), not its whole bounding box.  Measured
  *                               on the 3 M-splat scene: pairs -23 %, sort -0.2 ms, but the per-splat tile loops

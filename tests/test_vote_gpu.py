@@ -75,7 +75,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     sizes = [(480, 270)] * 9
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
-                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "shared_rcp": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
+                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -109,12 +109,52 @@ def test_project_extreme_exponents(gsx):
         cams.append({"fx": fx, "fy": fy, "width": 1920, "height": 1080, "rotation": R, "position": p})
     for shared in (1, 0):
         with gsx.Context(0) as c:
-            c.set_option("shared_rcp", shared)
+            c.set_option("fast_div", shared)
             c.upload_positions(pos)
             for cam in cams:
                 x, y = c.project_all(cam)
                 ox, oy = oracle.project_many(pos, cam)
                 assert np.array_equal(x, ox) and np.array_equal(y, oy), (shared, cam["fx"], cam["fy"])
+
+
+def test_certified_projection_equals_exact_divisions(gsx):
+    """The single-reciprocal path (fast_div=1) must give the very same pixels as the two IEEE divisions:
+    3 M Gaussians x 24 views GPU-vs-GPU, and points sitting ON and within a few ulps of pixel boundaries
+    (where the certified margin must hand over to the exact path) against the oracle."""
+    n = 3_000_000
+    pos = scene.make_positions(n, scene.BASE_SEED + 3)
+    cams = scene.make_cameras(200, 1920, 1080, convention="w2c")[::9][:24]
+    with gsx.Context(0) as fast, gsx.Context(0) as exact:
+        exact.set_option("fast_div", 0)
+        fast.upload_positions(pos)
+        exact.upload_positions(pos)
+        vis = 0
+        for cam in cams:
+            xf, yf = fast.project_all(cam)
+            xe, ye = exact.project_all(cam)
+            assert np.array_equal(xf, xe) and np.array_equal(yf, ye)
+            vis += int((xe >= 0).sum())
+        assert vis > 0.4 * n * len(cams)
+        # boundary points: camera with power-of-two focal so that x*f/z + w/2 is exact for dyadic x
+        cam = {"fx": 1024.0, "fy": 512.0, "width": 2048, "height": 1024, "rotation": np.eye(3).tolist(), "position": [0, 0, 0]}
+        k = np.arange(-1100, 1100, dtype=np.float64)
+        pts = []
+        for z in (1.0, 2.0, 0.5):
+            x = (k * z / 1024.0)
+            for dx in (0.0, 1e-7, -1e-7):
+                pts.append(np.stack([x + dx, (k % 400 - 200) * z / 512.0 + dx, np.full_like(k, z)], 1))
+        pts = np.concatenate(pts).astype(np.float32)
+        for sh in (0, 1, -1, 2, -2):                                  # neighbouring float32 values
+            q = pts.copy()
+            if sh:
+                q[:, 0] = np.nextafter(q[:, 0], np.float32(np.inf if sh > 0 else -np.inf)) if abs(sh) == 1 else \
+                    np.nextafter(np.nextafter(q[:, 0], np.float32(np.inf if sh > 0 else -np.inf)), np.float32(np.inf if sh > 0 else -np.inf))
+            ox, oy = oracle.project_many(q, cam)
+            for c in (fast, exact):
+                c.upload_positions(q)
+                x, y = c.project_all(cam)
+                assert np.array_equal(x, ox) and np.array_equal(y, oy)
+        assert (ox >= 0).sum() > 1000
 
 
 # ---- assign_labels ---------------------------------------------------------------------------------
@@ -398,6 +438,7 @@ def test_randomised_small_configurations(gsx):
             c.set_option("seg_tiled", int(rng.integers(0, 2)))
             c.set_option("vote_unroll", int(rng.choice([2, 4, 8])))
             c.set_option("lds_batch", int(rng.integers(0, 2)))
+            c.set_option("fast_div", int(rng.integers(0, 2)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
             for v in range(V):
