@@ -110,7 +110,7 @@ struct Ctx {
     int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %, net slower)
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
-    int opt_fast_div = 1;      // certified single-reciprocal projection with exact fallback (vote.hip project<>)
+    int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
 
     // vote
     bool vote_begun = false;

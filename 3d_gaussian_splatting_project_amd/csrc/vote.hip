@@ -91,7 +91,8 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
 //   whenever |px| <= 2^18, and far outside the frame (<= 2^16 pixels) otherwise.  If s^ is at least 2^-20 away
 //   from every integer, floor(px) == floor(s^) is CERTAIN, and so are `0 <= px < width` (integer width) and the
 //   truncation int(px).  A lane that is closer than that to an integer (~4e-6 of them), or whose arithmetic left
-//   the finite range, falls through to the exact divisions.  11 fewer fp64 instructions per visible pair.
+//   the finite range, or whose depth lies outside [2^-200, 2^200] (reciprocal not safely normal), falls through to
+//   the exact divisions.  11 fewer fp64 instructions per visible pair.
 enum { kDivExact = 0, kDivCertified = 1 };
 
 template <int DIV>
@@ -101,7 +102,8 @@ __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, 
     const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
     const double pc1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
     const double ax = vd.fx * pc0, ay = vd.fy * pc1;
-    if (DIV == kDivCertified) {
+    // the certificate below assumes a normal reciprocal: 2^-200 <= pc2 <= 2^200 (exponent field 823..1223)
+    if (DIV == kDivCertified && (unsigned)(((__double2hiint(pc2) >> 20) & 0x7ff) - 823) <= 400u) {
         double r = __builtin_amdgcn_rcp(pc2);
         r = __builtin_fma(__builtin_fma(-pc2, r, 1.0), r, r);
         r = __builtin_fma(__builtin_fma(-pc2, r, 1.0), r, r);

@@ -107,6 +107,10 @@ def test_project_extreme_exponents(gsx):
     for fx, fy, p in ((1e-300, 1e300, [0, 0, 0]), (1e300, 1e-300, [0, 0, -1e-30]), (3e150, 2e-160, [1e-20, -1e20, -1e-35]),
                       (1000.0, 1e-310, [0, 0, -1e-300]), (5e-324, 1e308, [0, 0, -1e-40])):
         cams.append({"fx": fx, "fy": fy, "width": 1920, "height": 1080, "rotation": R, "position": p})
+    # depth ~1e308: 1/depth is subnormal.  An unguarded reciprocal path would "certify" px = width/2 (odd width:
+    # fraction 0.5) although the true quotient is 0.5 and 1.0
+    cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-1e308, -1e308, -1e308]})
+    cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-4e307, -8e307, -1.6e308]})
     for shared in (1, 0):
         with gsx.Context(0) as c:
             c.set_option("fast_div", shared)
