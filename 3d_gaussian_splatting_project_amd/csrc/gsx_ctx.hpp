@@ -111,6 +111,8 @@ struct Ctx {
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
+    int opt_flat_project = 0;  // branchless projection block (exact divisions, one predicate at the end)
+    int opt_vote_gpt = 1;      // Gaussians per thread in the fused labels kernel (1 | 2)
 
     // vote
     bool vote_begun = false;

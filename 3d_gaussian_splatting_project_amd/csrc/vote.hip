@@ -93,11 +93,27 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
 //   truncation int(px).  A lane that is closer than that to an integer (~4e-6 of them), or whose arithmetic left
 //   the finite range, or whose depth lies outside [2^-200, 2^200] (reciprocal not safely normal), falls through to
 //   the exact divisions.  11 fewer fp64 instructions per visible pair.
-enum { kDivExact = 0, kDivCertified = 1 };
+// DIV == kDivFlat: the exact divisions again, but as ONE straight-line block: all three rows and both quotients are
+//   evaluated unconditionally and the reference's tests (:72, :80) become a single predicate at the end.  The
+//   branchy form serialises ~45 dependent fp64 instructions behind three divergent branches; here the three rows
+//   and the two quotients are independent chains the scheduler interleaves.  Same operations, same operands,
+//   same results; lanes the reference rejects early merely compute values nobody reads.
+enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2 };
 
 template <int DIV>
 __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
+    if (DIV == kDivFlat) {
+        const double q0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
+        const double q1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
+        const double fpx = (vd.fx * q0) / pc2 + vd.half_w;  // dls.py:76
+        const double fpy = (vd.fy * q1) / pc2 + vd.half_h;  // dls.py:77
+        const bool vis = (pc2 > 0.0) & (0.0 <= fpx) & (fpx < vd.width) & (0.0 <= fpy) & (fpy < vd.height);  // :72, :80
+        if (!vis) return false;
+        xi = (int)fpx;  // :81
+        yi = (int)fpy;
+        return true;
+    }
     if (!(pc2 > 0.0)) return false;  // `pc2 <= 0` -> None; a NaN depth fails the bounds test below anyway
     const double pc0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
     const double pc1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
@@ -128,8 +144,8 @@ __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, 
 }
 
 template <int DIV>
-__device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, double X, double Y, double Z) {
-    const ViewRegs vd = load_view(vp);
+__device__ __forceinline__ long long seg_index_regs(const ViewRegs& vd, const ViewDesc* __restrict__ vp, double X, double Y,
+                                                    double Z) {
     int xi, yi;
     if (!project<DIV>(vd, X, Y, Z, xi, yi)) return -1;
     if (!vd.unit_scale) {
@@ -142,6 +158,12 @@ __device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, 
     if (vd.seg_tw)  // 16x8-pixel tiles of 128 B: a compact patch of pixels is a compact set of cache lines
         return vd.seg_off + (((long long)(yi >> 3) * vd.seg_tw + (xi >> 4)) << 7) + ((yi & 7) << 4) + (xi & 15);
     return vd.seg_off + (long long)yi * vd.seg_w + xi;
+}
+
+template <int DIV>
+__device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, double X, double Y, double Z) {
+    const ViewRegs vd = load_view(vp);
+    return seg_index_regs<DIV>(vd, vp, X, Y, Z);
 }
 
 template <int DIV>
@@ -286,6 +308,144 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
         const long long o = p.perm ? (long long)p.perm[i] : i;
         labels[o] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
     }
+}
+
+// Software-pipelined variant (option vote_gpt=3): the seg-map bytes gathered for chunk k are consumed only after
+// the gathers of chunk k+1 have been issued, so the newest gather's latency overlaps a whole chunk of projection
+// arithmetic instead of stalling the wave right before the LDS updates.
+template <int U, int DIV>
+__global__ __launch_bounds__(kBlock) void vote_fused_labels_pipe_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                        int* __restrict__ labels) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;
+    uint8_t* h = reinterpret_cast<uint8_t*>(row);
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const double X = valid ? (double)p.x[i] : __builtin_nan("");
+    const double Y = valid ? (double)p.y[i] : 0.0;
+    const double Z = valid ? (double)p.z[i] : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+    int best = -1, bestc = 0;
+    // Gathers are UNCONDITIONAL (invisible lanes read pool[0] and are masked by `ok` when the votes are applied):
+    // a load under a divergent branch forces the compiler to wait with vmcnt(0), an unconditional one lets it
+    // count, so the previous chunk can be consumed while this chunk's gathers are still in flight.
+    auto gather = [&](int (&raw)[U], unsigned& ok, int vb) {
+        ok = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            long long off = -1;
+            if (v >= 0) off = seg_index<DIV>(views + v, X, Y, Z);
+            ok |= (off >= 0 ? 1u : 0u) << u;
+            // issued by hand so that the compiler neither waits for it nor touches the result early; the
+            // matching s_waitcnt is the asm statement at the top of apply()
+            asm volatile("global_load_ubyte %0, %1, off" : "=v"(raw[u]) : "v"(pool + (off >= 0 ? off : 0)) : "memory");
+        }
+    };
+    auto apply = [&](int (&raw)[U], unsigned ok, bool last) {
+        // vmcnt retires in order: everything but the U gathers issued after this chunk's has landed
+        static_assert(U == 2 || U == 4 || U == 8, "");
+        if (last) {
+            if (U == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[U > 4 ? 4 : 0]), "+v"(raw[U > 4 ? 5 : 1]), "+v"(raw[U > 4 ? 6 : 2]), "+v"(raw[U > 4 ? 7 : 3]) : : "memory");
+            else if (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[U > 2 ? 2 : 0]), "+v"(raw[U > 2 ? 3 : 1]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]) : : "memory");
+        } else {
+            if (U == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[U > 4 ? 4 : 0]), "+v"(raw[U > 4 ? 5 : 1]), "+v"(raw[U > 4 ? 6 : 2]), "+v"(raw[U > 4 ? 7 : 3]) : : "memory");
+            else if (U == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[U > 2 ? 2 : 0]), "+v"(raw[U > 2 ? 3 : 1]) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw[0]), "+v"(raw[1]) : : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if ((ok >> u) & 1u) {
+                const int c = h[raw[u]] + 1;
+                h[raw[u]] = (uint8_t)c;
+                if (c >= bestc) {
+                    bestc = c;
+                    best = raw[u];
+                }
+            }
+        }
+    };
+    // two register sets, no copies: chunk order a0 b0 a1 b1 .. is the reverse view order throughout
+    int a[U], b[U];
+    unsigned oka = 0, okb = 0;
+    gather(b, okb, 0);  // U dummy gathers (masked): the counter arithmetic below then holds from the first trip on
+    for (int vb = p.nviews; vb > 0; vb -= 2 * U) {
+        gather(a, oka, vb);
+        apply(b, okb, false);
+        gather(b, okb, vb - U);
+        apply(a, oka, false);
+    }
+    apply(b, okb, true);
+    if (valid) {
+        const long long o = p.perm ? (long long)p.perm[i] : i;
+        labels[o] = best - 1 + (best < 0);
+    }
+}
+
+// Two Gaussians per thread (option vote_gpt=2): 128-thread workgroups, the same 256 histogram rows of LDS per
+// workgroup, but every batch of scalar view loads and every scalar instruction now serves 128 projections per
+// wave instead of 64, and a wave has two independent dependency chains to hide its own LDS / gather latency.
+static constexpr int kBlock2 = 128;
+template <int U, int DIV>
+__global__ __launch_bounds__(kBlock2) void vote_fused_labels2_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                     int* __restrict__ labels) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* row0 = lds + threadIdx.x * p.stride_dw;
+    uint32_t* row1 = lds + (threadIdx.x + kBlock2) * p.stride_dw;
+    for (int k = 0; k < p.stride_dw; ++k) row0[k] = row1[k] = 0;  // thread-private: no barrier needed
+    uint8_t* h0 = reinterpret_cast<uint8_t*>(row0);
+    uint8_t* h1 = reinterpret_cast<uint8_t*>(row1);
+
+    const long long i0 = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const long long i1 = i0 + kBlock2;
+    const bool valid0 = i0 < p.n, valid1 = i1 < p.n;
+    const double X0 = valid0 ? (double)p.x[i0] : __builtin_nan("");
+    const double Y0 = valid0 ? (double)p.y[i0] : 0.0;
+    const double Z0 = valid0 ? (double)p.z[i0] : 0.0;
+    const double X1 = valid1 ? (double)p.x[i1] : __builtin_nan("");
+    const double Y1 = valid1 ? (double)p.y[i1] : 0.0;
+    const double Z1 = valid1 ? (double)p.z[i1] : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+
+    int best0 = -1, bestc0 = 0, best1 = -1, bestc1 = 0;
+    for (int vb = p.nviews; vb > 0; vb -= U) {  // views vb-1, vb-2, .. (reverse order)
+        int bin0[U], bin1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            bin0[u] = bin1[u] = -1;
+            if (v >= 0) {  // wave-uniform
+                const ViewRegs vd = load_view(views + v);
+                const long long off0 = seg_index_regs<DIV>(vd, views + v, X0, Y0, Z0);
+                const long long off1 = seg_index_regs<DIV>(vd, views + v, X1, Y1, Z1);
+                if (off0 >= 0) bin0[u] = pool[off0];
+                if (off1 >= 0) bin1[u] = pool[off1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (bin0[u] >= 0) {
+                const int c = h0[bin0[u]] + 1;  // dls.py:295
+                h0[bin0[u]] = (uint8_t)c;
+                if (c >= bestc0) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
+                    bestc0 = c;
+                    best0 = bin0[u];
+                }
+            }
+            if (bin1[u] >= 0) {
+                const int c = h1[bin1[u]] + 1;
+                h1[bin1[u]] = (uint8_t)c;
+                if (c >= bestc1) {
+                    bestc1 = c;
+                    best1 = bin1[u];
+                }
+            }
+        }
+    }
+    if (valid0) labels[p.perm ? (long long)p.perm[i0] : i0] = best0 - 1 + (best0 < 0);
+    if (valid1) labels[p.perm ? (long long)p.perm[i1] : i1] = best1 - 1 + (best1 < 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -644,6 +804,7 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.unit_scale = (vd.wscale == 1.0 && vd.hscale == 1.0 && cam->width <= seg_w && cam->height <= seg_h) ? 1 : 0;
 }
 
+static inline int div_mode(const Ctx* c) { return c->opt_flat_project ? kDivFlat : c->opt_fast_div ? kDivCertified : kDivExact; }
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
@@ -660,7 +821,10 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
-        if (c->opt_fast_div)
+        if (div_mode(c) == kDivFlat)
+            hipLaunchKernelGGL(project_kernel<kDivFlat>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+        else if (div_mode(c) == kDivCertified)
             hipLaunchKernelGGL(project_kernel<kDivCertified>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
                                dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         else
@@ -893,12 +1057,12 @@ int vote_flush(Ctx* c) {
         const int fresh = (c->planes_zero || c->planes_stale) ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
-            auto k = c->opt_fast_div ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
+            auto k = div_mode(c) == kDivFlat ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint16_t>(),
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
-            auto k = c->opt_fast_div ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
+            auto k = div_mode(c) == kDivFlat ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
                                c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
@@ -982,17 +1146,27 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             // kernel variants: unroll U in {2,4,8} x division mode x batched LDS reads
             using K = void (*)(FusedParams, const ViewDesc*, int*);
             const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
-            static const K table[3][2][2] = {
-                {{vote_fused_labels_kernel<2, kDivExact, false>, vote_fused_labels_kernel<2, kDivExact, true>},
-                 {vote_fused_labels_kernel<2, kDivCertified, false>, vote_fused_labels_kernel<2, kDivCertified, true>}},
-                {{vote_fused_labels_kernel<4, kDivExact, false>, vote_fused_labels_kernel<4, kDivExact, true>},
-                 {vote_fused_labels_kernel<4, kDivCertified, false>, vote_fused_labels_kernel<4, kDivCertified, true>}},
-                {{vote_fused_labels_kernel<8, kDivExact, false>, vote_fused_labels_kernel<8, kDivExact, true>},
-                 {vote_fused_labels_kernel<8, kDivCertified, false>, vote_fused_labels_kernel<8, kDivCertified, true>}}};
-            K k = table[ui][c->opt_fast_div ? 1 : 0][c->opt_lds_batch ? 1 : 0];
+#define GSX_ROW(U_) \
+    {{vote_fused_labels_kernel<U_, kDivExact, false>, vote_fused_labels_kernel<U_, kDivExact, true>},         \
+     {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
+     {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>}}
+            static const K table[3][3][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
+#undef GSX_ROW
+            static const K table2[3][3] = {
+                {vote_fused_labels2_kernel<2, kDivExact>, vote_fused_labels2_kernel<2, kDivCertified>, vote_fused_labels2_kernel<2, kDivFlat>},
+                {vote_fused_labels2_kernel<4, kDivExact>, vote_fused_labels2_kernel<4, kDivCertified>, vote_fused_labels2_kernel<4, kDivFlat>},
+                {vote_fused_labels2_kernel<8, kDivExact>, vote_fused_labels2_kernel<8, kDivCertified>, vote_fused_labels2_kernel<8, kDivFlat>}};
+            static const K table3[3][3] = {
+                {vote_fused_labels_pipe_kernel<2, kDivExact>, vote_fused_labels_pipe_kernel<2, kDivCertified>, vote_fused_labels_pipe_kernel<2, kDivFlat>},
+                {vote_fused_labels_pipe_kernel<4, kDivExact>, vote_fused_labels_pipe_kernel<4, kDivCertified>, vote_fused_labels_pipe_kernel<4, kDivFlat>},
+                {vote_fused_labels_pipe_kernel<8, kDivExact>, vote_fused_labels_pipe_kernel<8, kDivCertified>, vote_fused_labels_pipe_kernel<8, kDivFlat>}};
+            const bool two = c->opt_vote_gpt == 2;
+            const int dm = div_mode(c);
+            K k = c->opt_vote_gpt == 3 ? table3[ui][dm] : two ? table2[ui][dm] : table[ui][dm][c->opt_lds_batch ? 1 : 0];
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(two ? kBlock2 : kBlock), lds, c->stream, p, p.views,
+                               c->labels.as<int>());
             GSX_HIP(c, hipGetLastError());
         }
         return labels_to_host(c, labels_out);
@@ -1033,7 +1207,7 @@ int vote_flush_counts(Ctx* c) {
     if (c->n > 0) {
         FusedParams p = fused_params(c, 1);
         const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-        auto k = c->opt_fast_div ? vote_fused_counts_kernel<kUnroll, kDivCertified> : vote_fused_counts_kernel<kUnroll, kDivExact>;
+        auto k = div_mode(c) == kDivFlat ? vote_fused_counts_kernel<kUnroll, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified> : vote_fused_counts_kernel<kUnroll, kDivExact>;
         if ((rc = set_lds(c, k, lds))) return rc;
         ProfScope ps(c, "vote_fused_counts");
         hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),

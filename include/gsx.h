@@ -73,6 +73,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 2, 4, 8
+ *   "vote_gpt"     (default 1)  Gaussians per thread of the single-GPU vote kernel: 1 (256-thread workgroups) or
+ *                               2 (128-thread workgroups, two independent chains per lane)
  *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
  *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
  *   "fast_div"     (default 0)  projection through ONE reciprocal with a certified margin; lanes within 2^-20 of a

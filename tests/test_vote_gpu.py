@@ -75,7 +75,12 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     sizes = [(480, 270)] * 9
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
-                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0}):
+                 {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
+                 {"vote_gpt": 2}, {"vote_gpt": 2, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
+                 {"vote_gpt": 2, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0},
+                 {"flat_project": 1}, {"flat_project": 1, "vote_unroll": 2, "spatial_sort": 0}, {"flat_project": 1, "vote_gpt": 2},
+                 {"vote_gpt": 3}, {"vote_gpt": 3, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
+                 {"vote_gpt": 3, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -111,9 +116,9 @@ def test_project_extreme_exponents(gsx):
     # fraction 0.5) although the true quotient is 0.5 and 1.0
     cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-1e308, -1e308, -1e308]})
     cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-4e307, -8e307, -1.6e308]})
-    for shared in (1, 0):
+    for shared in (("fast_div", 1), ("fast_div", 0), ("flat_project", 1)):
         with gsx.Context(0) as c:
-            c.set_option("fast_div", shared)
+            c.set_option(*shared)
             c.upload_positions(pos)
             for cam in cams:
                 x, y = c.project_all(cam)
@@ -122,21 +127,29 @@ def test_project_extreme_exponents(gsx):
 
 
 def test_certified_projection_equals_exact_divisions(gsx):
-    """The single-reciprocal path (fast_div=1) must give the very same pixels as the two IEEE divisions:
+    """The single-reciprocal path (fast_div=1) and the branchless block (flat_project=1) must give the very same
+    pixels as the branchy two-division form:
     3 M Gaussians x 24 views GPU-vs-GPU, and points sitting ON and within a few ulps of pixel boundaries
     (where the certified margin must hand over to the exact path) against the oracle."""
     n = 3_000_000
     pos = scene.make_positions(n, scene.BASE_SEED + 3)
     cams = scene.make_cameras(200, 1920, 1080, convention="w2c")[::9][:24]
-    with gsx.Context(0) as fast, gsx.Context(0) as exact:
+    with gsx.Context(0) as fast, gsx.Context(0) as exact, gsx.Context(0) as flat:
         exact.set_option("fast_div", 0)
+        exact.set_option("flat_project", 0)
+        fast.set_option("fast_div", 1)
+        fast.set_option("flat_project", 0)
+        flat.set_option("flat_project", 1)
         fast.upload_positions(pos)
         exact.upload_positions(pos)
+        flat.upload_positions(pos)
         vis = 0
         for cam in cams:
             xf, yf = fast.project_all(cam)
             xe, ye = exact.project_all(cam)
+            xl, yl = flat.project_all(cam)
             assert np.array_equal(xf, xe) and np.array_equal(yf, ye)
+            assert np.array_equal(xl, xe) and np.array_equal(yl, ye)
             vis += int((xe >= 0).sum())
         assert vis > 0.4 * n * len(cams)
         # boundary points: camera with power-of-two focal so that x*f/z + w/2 is exact for dyadic x
@@ -154,7 +167,7 @@ def test_certified_projection_equals_exact_divisions(gsx):
                 q[:, 0] = np.nextafter(q[:, 0], np.float32(np.inf if sh > 0 else -np.inf)) if abs(sh) == 1 else \
                     np.nextafter(np.nextafter(q[:, 0], np.float32(np.inf if sh > 0 else -np.inf)), np.float32(np.inf if sh > 0 else -np.inf))
             ox, oy = oracle.project_many(q, cam)
-            for c in (fast, exact):
+            for c in (fast, exact, flat):
                 c.upload_positions(q)
                 x, y = c.project_all(cam)
                 assert np.array_equal(x, ox) and np.array_equal(y, oy)
@@ -443,6 +456,8 @@ def test_randomised_small_configurations(gsx):
             c.set_option("vote_unroll", int(rng.choice([2, 4, 8])))
             c.set_option("lds_batch", int(rng.integers(0, 2)))
             c.set_option("fast_div", int(rng.integers(0, 2)))
+            c.set_option("vote_gpt", int(rng.integers(1, 4)))
+            c.set_option("flat_project", int(rng.integers(0, 2)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
             for v in range(V):
