@@ -159,10 +159,6 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "fast_div") c->opt_fast_div = value != 0;
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "flat_project") c->opt_flat_project = value != 0;
-    else if (k == "vote_gpt") {
-        if (value < 1 || value > 3) return gsx::fail(c, GSX_E_INVALID, "set_option: vote_gpt must be 1, 2 or 3");
-        c->opt_vote_gpt = (int)value;
-    }
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)
             return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 2, 4 or 8");

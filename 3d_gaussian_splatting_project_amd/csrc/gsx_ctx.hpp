@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -64,22 +65,26 @@ struct DevBuf {
 };
 
 // ---- per-view descriptor read by the kernels through scalar (wave-uniform) loads ------------------
-struct alignas(16) ViewDesc {
+struct alignas(64) ViewDesc {
     // ---- hot part: loaded in ONE batch of scalar loads per view (vote.hip load_view) ----
     double R[9];       // cameras.json rotation, row-major                         (dls.py:60)
     double t[3];       // (-R) @ p in the dgemv association of the oracle           (dls.py:66)
     double fx, fy;     //                                                           (dls.py:54-55)
     double half_w, half_h;  // width/2, height/2                                    (dls.py:76-77)
     double width, height;   // bounds of the visibility test                        (dls.py:80)
-    long long seg_off;      // byte offset of this view's u8 map in the seg pool
+    long long seg_off;      // host copy: byte offset of this view's u8 map in the seg pool; device copy
+                            // (sync_views): the map's absolute address
     int seg_w;
     int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
-    int seg_tw;      // 16x8 tiles per map row (0: row-major map)
-    int cam_w, cam_h;  // camera width / height as integers (visibility test of the certified path)
+    // ---- 16 more hot bytes ----
+    int seg_row_bytes;  // bytes per strip of 16 pixel columns (0: row-major map)
+    int seg_h;          // (cold: scale + clamp path only)
+    int cam_w, cam_h;   // camera width / height as integers (visibility test of the certified path)
+    int pad_[4];
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
-    int seg_h;
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
 };
+static_assert(sizeof(ViewDesc) == 256 && offsetof(ViewDesc, wscale) == 192, "ViewDesc layout");
 
 struct ProfEvent {
     int name_id;
@@ -111,8 +116,7 @@ struct Ctx {
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
-    int opt_flat_project = 0;  // branchless projection block (exact divisions, one predicate at the end)
-    int opt_vote_gpt = 1;      // Gaussians per thread in the fused labels kernel (1 | 2)
+    int opt_flat_project = 1;  // branchless projection block (exact divisions, one predicate at the end)
 
     // vote
     bool vote_begun = false;
@@ -124,6 +128,7 @@ struct Ctx {
     int64_t sn = 0;            // Gaussians per slab (multiple of 256); n_pad = slabs * sn
     std::vector<ViewDesc> views;
     bool views_dirty = true;  // host views newer than d_views
+    bool views_simple = false;  // every staged view: unit scale + tiled map (set by sync_views)
     DevBuf d_views;
     DevBuf segpool;
     size_t seg_used = 0;

@@ -7,10 +7,10 @@
 //
 // Data layout in HBM
 //   positions      SoA  x[n], y[n], z[n] f32                      (coalesced 4 B/lane loads)
-//   views          ViewDesc[V], 192 B each, wave-uniform -> scalar loads, operands live in SGPRs
-//   seg pool       u8 maps, value = label+1 (bin index), one after another, each stored as 16x8-pixel
-//                  tiles of 128 B (one L2 line): the pixels a wave gathers are a compact patch, so they
-//                  fall into few lines; 1 B gathers
+//   views          ViewDesc[V], 256 B each (176 hot), wave-uniform -> four scalar loads, operands live in SGPRs
+//   seg pool       u8 maps, value = label+1 (bin index), one after another, each stored as strips of 16 pixel
+//                  columns (rows of a strip back to back, 16 B each; 8 rows = one 128-B L2 line): the pixels
+//                  a wave gathers are a compact patch, so they fall into few lines; 1 B gathers
 //   planes         cnt[slab][bins][sn], fv[slab][bins][sn]  u8 or u16 (16 bit only for the all-reduce
 //                  protocol with > 255 views in total): bin-major so that a wave's 64 Gaussians touch 64
 //                  consecutive elements of a row; slab = one rank's share in the all-to-all protocols
@@ -34,6 +34,8 @@
 #include <cmath>
 #include <cstring>
 
+#include <type_traits>
+
 #include "gsx_ctx.hpp"
 
 namespace gsx {
@@ -50,31 +52,59 @@ static constexpr int kMaxBatch = 255;  // views per fused launch: LDS counters a
 struct ViewRegs {
     double R[9], t[3], fx, fy, half_w, half_h, width, height;
     long long seg_off;
-    int seg_w, unit_scale, seg_tw, cam_w, cam_h;
+    int seg_w, unit_scale, seg_row_bytes, cam_w, cam_h;
 };
 
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double chunk_f64(const v16i& v, int k) {
+    v2i t;
+    t.x = v[2 * k];
+    t.y = v[2 * k + 1];
+    return __builtin_bit_cast(double, t);
+}
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+// The hot 176 bytes of a ViewDesc as four scalar loads (x16, x16, x8, x4), pinned as whole register tuples: the
+// fields below are sub-registers of those tuples, no scalar move is spent on them.  (Pinning the 24 fields one
+// by one cost 15 s_mov per view; the scalar unit is shared by the four SIMDs of a CU and every wave issues at
+// most one instruction per turn, so scalar bookkeeping was costing as much as the fp64 arithmetic.)
 __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
+    static_assert(offsetof(ViewDesc, R) == 0 && offsetof(ViewDesc, t) == 72 && offsetof(ViewDesc, fx) == 96 &&
+                      offsetof(ViewDesc, half_w) == 112 && offsetof(ViewDesc, width) == 128 &&
+                      offsetof(ViewDesc, seg_off) == 144 && offsetof(ViewDesc, seg_w) == 152 &&
+                      offsetof(ViewDesc, unit_scale) == 156 && offsetof(ViewDesc, seg_row_bytes) == 160 &&
+                      offsetof(ViewDesc, cam_w) == 168 && sizeof(ViewDesc) % 64 == 0,
+                  "load_view reads the hot part of ViewDesc as 64 + 64 + 32 + 16 bytes");
+    const char* q = reinterpret_cast<const char*>(vp);
+    v16i a = *reinterpret_cast<const v16i*>(q);
+    v16i b = *reinterpret_cast<const v16i*>(q + 64);
+    v8i c = *reinterpret_cast<const v8i*>(q + 128);
+    v4i d = *reinterpret_cast<const v4i*>(q + 160);
+    asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
     ViewRegs r;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) r.R[k] = vp->R[k];
+    for (int k = 0; k < 8; ++k) r.R[k] = chunk_f64(a, k);
+    r.R[8] = chunk_f64(b, 0);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) r.t[k] = vp->t[k];
-    r.fx = vp->fx;
-    r.fy = vp->fy;
-    r.half_w = vp->half_w;
-    r.half_h = vp->half_h;
-    r.width = vp->width;
-    r.height = vp->height;
-    r.seg_off = vp->seg_off;
-    r.seg_w = vp->seg_w;
-    r.unit_scale = vp->unit_scale;
-    r.seg_tw = vp->seg_tw;
-    r.cam_w = vp->cam_w;
-    r.cam_h = vp->cam_h;
-    asm volatile("" : "+s"(r.R[0]), "+s"(r.R[1]), "+s"(r.R[2]), "+s"(r.R[3]), "+s"(r.R[4]), "+s"(r.R[5]), "+s"(r.R[6]),
-                      "+s"(r.R[7]), "+s"(r.R[8]), "+s"(r.t[0]), "+s"(r.t[1]), "+s"(r.t[2]), "+s"(r.fx), "+s"(r.fy),
-                      "+s"(r.half_w), "+s"(r.half_h), "+s"(r.width), "+s"(r.height), "+s"(r.seg_off), "+s"(r.seg_w),
-                      "+s"(r.unit_scale), "+s"(r.seg_tw), "+s"(r.cam_w), "+s"(r.cam_h));
+    for (int k = 0; k < 3; ++k) r.t[k] = chunk_f64(b, 1 + k);
+    r.fx = chunk_f64(b, 4);
+    r.fy = chunk_f64(b, 5);
+    r.half_w = chunk_f64(b, 6);
+    r.half_h = chunk_f64(b, 7);
+    v2i t;
+    t.x = c[0], t.y = c[1];
+    r.width = __builtin_bit_cast(double, t);
+    t.x = c[2], t.y = c[3];
+    r.height = __builtin_bit_cast(double, t);
+    t.x = c[4], t.y = c[5];
+    r.seg_off = __builtin_bit_cast(long long, t);
+    r.seg_w = c[6];
+    r.unit_scale = c[7];
+    r.seg_row_bytes = d[0];
+    r.cam_w = d[2];
+    r.cam_h = d[3];
     return r;
 }
 
@@ -98,16 +128,52 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
 //   branchy form serialises ~45 dependent fp64 instructions behind three divergent branches; here the three rows
 //   and the two quotients are independent chains the scheduler interleaves.  Same operations, same operands,
 //   same results; lanes the reference rejects early merely compute values nobody reads.
-enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2 };
+// DIV == kDivFlatSimple: kDivFlat for a batch whose views ALL have unit scale and tiled maps (the host checks): the
+//   two wave-uniform tests per view disappear from the instruction stream.
+enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2, kDivFlatSimple = 3 };
+
+// Two IEEE-754 divisions by the same denominator, bit-identical to `ax / b` and `ay / b`.
+// hipcc expands an fp64 division into div_scale(den), rcp, two Newton steps, div_scale(num), mul, fma, div_fmas,
+// div_fixup.  Everything up to the refined reciprocal depends only on the SCALED denominator, which is the same
+// for both quotients unless v_div_scale rescales for an extreme exponent gap; so the reciprocal chain (v_rcp_f64,
+// which costs as much as 3.4 fp64 FMAs on gfx950, plus 4 FMAs) is evaluated once.  Lanes whose two scaled
+// denominators differ redo the second quotient with the plain division (extreme-exponent tests only).
+__device__ __forceinline__ void div2_shared(double ax, double ay, double b, double& qx, double& qy) {
+    bool unused, vx, vy;
+    const double sdx = __builtin_amdgcn_div_scale(ax, b, false, &unused);
+    const double sdy = __builtin_amdgcn_div_scale(ay, b, false, &unused);
+    const double nsd = -sdx;
+    double r = __builtin_amdgcn_rcp(sdx);
+    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(nsd, r, 1.0), r);
+    const double snx = __builtin_amdgcn_div_scale(ax, b, true, &vx);
+    const double mx = snx * r;
+    qx = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, mx, snx), r, mx, vx), b, ax);
+    const double sny = __builtin_amdgcn_div_scale(ay, b, true, &vy);
+    const double my = sny * r;
+    qy = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nsd, my, sny), r, my, vy), b, ay);
+    // wave-uniform test on purpose: behind a per-lane `if` the compiler turns the fallback into a select and
+    // evaluates the second reciprocal chain unconditionally
+    const bool differ = __double_as_longlong(sdx) != __double_as_longlong(sdy);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(differ) != 0, 0)) {
+        const double slow = ay / b;
+        qy = differ ? slow : qy;
+    }
+}
 
 template <int DIV>
 __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
-    if (DIV == kDivFlat) {
+    if (DIV == kDivFlat || DIV == kDivFlatSimple) {
+        // one wave-uniform early-out keeps what matters of the branchy form: a wave whose 64 Gaussians are all
+        // behind the camera (Morton order makes that the common way to be culled) skips the view
+        if (__builtin_amdgcn_ballot_w64(pc2 > 0.0) == 0) return false;
         const double q0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
         const double q1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
-        const double fpx = (vd.fx * q0) / pc2 + vd.half_w;  // dls.py:76
-        const double fpy = (vd.fy * q1) / pc2 + vd.half_h;  // dls.py:77
+        double qx, qy;
+        div2_shared(vd.fx * q0, vd.fy * q1, pc2, qx, qy);
+        const double fpx = qx + vd.half_w;  // dls.py:76
+        const double fpy = qy + vd.half_h;  // dls.py:77
         const bool vis = (pc2 > 0.0) & (0.0 <= fpx) & (fpx < vd.width) & (0.0 <= fpy) & (fpy < vd.height);  // :72, :80
         if (!vis) return false;
         xi = (int)fpx;  // :81
@@ -143,27 +209,45 @@ __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, 
     return true;
 }
 
+// The vote of one Gaussian in one view: the map byte (bin = label + 1) under its projection, or -1 where the
+// reference skips the pair (dls.py:278-279).  All in-map offsets are 32-bit (maps are <= 65535 x 65535, checked in
+// vote_view), added to the view's wave-uniform base pointer: the gather is `global_load_ubyte v, v_off, s[base]`.
 template <int DIV>
-__device__ __forceinline__ long long seg_index_regs(const ViewRegs& vd, const ViewDesc* __restrict__ vp, double X, double Y,
-                                                    double Z) {
+__device__ __forceinline__ int seg_bin_regs(const ViewRegs& vd, const ViewDesc* __restrict__ vp,
+                                            const uint8_t* __restrict__ pool, double X, double Y, double Z) {
     int xi, yi;
-    if (!project<DIV>(vd, X, Y, Z, xi, yi)) return -1;
-    if (!vd.unit_scale) {
-        const double xs = trunc((double)xi * vp->wscale);  // :281
-        const double ys = trunc((double)yi * vp->hscale);  // :282
-        const int seg_h = vp->seg_h;
-        xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
-        yi = ys > (double)(seg_h - 1) ? seg_h - 1 : (int)ys;        // :286
+    int bin = -1;
+    if (project<DIV>(vd, X, Y, Z, xi, yi)) {
+        constexpr bool kSimple = DIV == kDivFlatSimple;
+        if (!kSimple && !vd.unit_scale) {
+            const double xs = trunc((double)xi * vp->wscale);  // :281
+            const double ys = trunc((double)yi * vp->hscale);  // :282
+            const int seg_h = vp->seg_h;
+            xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
+            yi = ys > (double)(seg_h - 1) ? seg_h - 1 : (int)ys;        // :286
+        }
+        unsigned off;
+        if (kSimple || vd.seg_row_bytes) {
+            // strips of 16 pixel columns, rows of a strip back to back (16 B each): any 8 consecutive rows of a strip
+            // are one 128-B line, so a compact patch of pixels is a compact set of cache lines, and the offset is
+            // (xi>>4) * strip_bytes + (yi<<4) + (xi&15): four integer instructions
+            off = __umul24((unsigned)xi >> 4, (unsigned)vd.seg_row_bytes) + ((unsigned)xi & 15u) + ((unsigned)yi << 4);
+        } else {
+            off = __umul24((unsigned)yi, (unsigned)vd.seg_w) + (unsigned)xi;
+        }
+        // the device copy of the descriptor holds the map's absolute address; say "global" explicitly, a pointer made
+        // from an integer would otherwise be a FLAT one (flat loads also count in lgkmcnt and stall the scalar waits)
+        typedef const __attribute__((address_space(1))) uint8_t* global_u8;
+        bin = ((global_u8)(unsigned long long)vd.seg_off)[off];
     }
-    if (vd.seg_tw)  // 16x8-pixel tiles of 128 B: a compact patch of pixels is a compact set of cache lines
-        return vd.seg_off + (((long long)(yi >> 3) * vd.seg_tw + (xi >> 4)) << 7) + ((yi & 7) << 4) + (xi & 15);
-    return vd.seg_off + (long long)yi * vd.seg_w + xi;
+    return bin;
 }
 
 template <int DIV>
-__device__ __forceinline__ long long seg_index(const ViewDesc* __restrict__ vp, double X, double Y, double Z) {
+__device__ __forceinline__ int seg_bin(const ViewDesc* __restrict__ vp, const uint8_t* __restrict__ pool, double X, double Y,
+                                       double Z) {
     const ViewRegs vd = load_view(vp);
-    return seg_index_regs<DIV>(vd, vp, X, Y, Z);
+    return seg_bin_regs<DIV>(vd, vp, pool, X, Y, Z);
 }
 
 template <int DIV>
@@ -215,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ 
         }
     }
     long long o;
-    if (tiles_w) o = (((long long)(y >> 3) * tiles_w + (x0 >> 4)) << 7) + ((y & 7) << 4) + (x0 & 15);
+    if (tiles_w) o = (long long)(x0 >> 4) * tiles_w + ((long long)y << 4) + (x0 & 15);  // tiles_w: bytes per 16-column strip
     else o = (long long)y * w + x0;
     if (tiles_w || (((w & 3) == 0))) {
         *reinterpret_cast<uint32_t*>(out + o) = packed;  // tiled rows are 16 B, maps start 256-B aligned
@@ -260,16 +344,14 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 
     int best = -1;  // bin of the current winner
     int bestc = 0;
-    for (int vb = p.nviews; vb > 0; vb -= U) {  // views vb-1, vb-2, .. (reverse order)
+    // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
         int bin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int v = vb - 1 - u;
-            bin[u] = -1;
-            if (v >= 0) {  // wave-uniform
-                const long long off = seg_index<DIV>(views + v, X, Y, Z);
-                if (off >= 0) bin[u] = pool[off];
-            }
+            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
         }
         if (LDS_BATCH) {
             // one LDS round trip for the whole chunk: read the U counters first, resolve repeats of a bin
@@ -303,149 +385,14 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
                 }
             }
         }
-    }
+        };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
     if (valid) {
         const long long o = p.perm ? (long long)p.perm[i] : i;
         labels[o] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
     }
-}
-
-// Software-pipelined variant (option vote_gpt=3): the seg-map bytes gathered for chunk k are consumed only after
-// the gathers of chunk k+1 have been issued, so the newest gather's latency overlaps a whole chunk of projection
-// arithmetic instead of stalling the wave right before the LDS updates.
-template <int U, int DIV>
-__global__ __launch_bounds__(kBlock) void vote_fused_labels_pipe_kernel(FusedParams p, const ViewDesc* __restrict__ views,
-                                                                        int* __restrict__ labels) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* row = lds + threadIdx.x * p.stride_dw;
-    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;
-    uint8_t* h = reinterpret_cast<uint8_t*>(row);
-    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
-    const bool valid = i < p.n;
-    const double X = valid ? (double)p.x[i] : __builtin_nan("");
-    const double Y = valid ? (double)p.y[i] : 0.0;
-    const double Z = valid ? (double)p.z[i] : 0.0;
-    const uint8_t* __restrict__ pool = p.pool;
-    int best = -1, bestc = 0;
-    // Gathers are UNCONDITIONAL (invisible lanes read pool[0] and are masked by `ok` when the votes are applied):
-    // a load under a divergent branch forces the compiler to wait with vmcnt(0), an unconditional one lets it
-    // count, so the previous chunk can be consumed while this chunk's gathers are still in flight.
-    auto gather = [&](int (&raw)[U], unsigned& ok, int vb) {
-        ok = 0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb - 1 - u;
-            long long off = -1;
-            if (v >= 0) off = seg_index<DIV>(views + v, X, Y, Z);
-            ok |= (off >= 0 ? 1u : 0u) << u;
-            // issued by hand so that the compiler neither waits for it nor touches the result early; the
-            // matching s_waitcnt is the asm statement at the top of apply()
-            asm volatile("global_load_ubyte %0, %1, off" : "=v"(raw[u]) : "v"(pool + (off >= 0 ? off : 0)) : "memory");
-        }
-    };
-    auto apply = [&](int (&raw)[U], unsigned ok, bool last) {
-        // vmcnt retires in order: everything but the U gathers issued after this chunk's has landed
-        static_assert(U == 2 || U == 4 || U == 8, "");
-        if (last) {
-            if (U == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[U > 4 ? 4 : 0]), "+v"(raw[U > 4 ? 5 : 1]), "+v"(raw[U > 4 ? 6 : 2]), "+v"(raw[U > 4 ? 7 : 3]) : : "memory");
-            else if (U == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[U > 2 ? 2 : 0]), "+v"(raw[U > 2 ? 3 : 1]) : : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]) : : "memory");
-        } else {
-            if (U == 8) asm volatile("s_waitcnt vmcnt(8)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[U > 4 ? 4 : 0]), "+v"(raw[U > 4 ? 5 : 1]), "+v"(raw[U > 4 ? 6 : 2]), "+v"(raw[U > 4 ? 7 : 3]) : : "memory");
-            else if (U == 4) asm volatile("s_waitcnt vmcnt(4)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[U > 2 ? 2 : 0]), "+v"(raw[U > 2 ? 3 : 1]) : : "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw[0]), "+v"(raw[1]) : : "memory");
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if ((ok >> u) & 1u) {
-                const int c = h[raw[u]] + 1;
-                h[raw[u]] = (uint8_t)c;
-                if (c >= bestc) {
-                    bestc = c;
-                    best = raw[u];
-                }
-            }
-        }
-    };
-    // two register sets, no copies: chunk order a0 b0 a1 b1 .. is the reverse view order throughout
-    int a[U], b[U];
-    unsigned oka = 0, okb = 0;
-    gather(b, okb, 0);  // U dummy gathers (masked): the counter arithmetic below then holds from the first trip on
-    for (int vb = p.nviews; vb > 0; vb -= 2 * U) {
-        gather(a, oka, vb);
-        apply(b, okb, false);
-        gather(b, okb, vb - U);
-        apply(a, oka, false);
-    }
-    apply(b, okb, true);
-    if (valid) {
-        const long long o = p.perm ? (long long)p.perm[i] : i;
-        labels[o] = best - 1 + (best < 0);
-    }
-}
-
-// Two Gaussians per thread (option vote_gpt=2): 128-thread workgroups, the same 256 histogram rows of LDS per
-// workgroup, but every batch of scalar view loads and every scalar instruction now serves 128 projections per
-// wave instead of 64, and a wave has two independent dependency chains to hide its own LDS / gather latency.
-static constexpr int kBlock2 = 128;
-template <int U, int DIV>
-__global__ __launch_bounds__(kBlock2) void vote_fused_labels2_kernel(FusedParams p, const ViewDesc* __restrict__ views,
-                                                                     int* __restrict__ labels) {
-    extern __shared__ uint32_t lds[];
-    uint32_t* row0 = lds + threadIdx.x * p.stride_dw;
-    uint32_t* row1 = lds + (threadIdx.x + kBlock2) * p.stride_dw;
-    for (int k = 0; k < p.stride_dw; ++k) row0[k] = row1[k] = 0;  // thread-private: no barrier needed
-    uint8_t* h0 = reinterpret_cast<uint8_t*>(row0);
-    uint8_t* h1 = reinterpret_cast<uint8_t*>(row1);
-
-    const long long i0 = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
-    const long long i1 = i0 + kBlock2;
-    const bool valid0 = i0 < p.n, valid1 = i1 < p.n;
-    const double X0 = valid0 ? (double)p.x[i0] : __builtin_nan("");
-    const double Y0 = valid0 ? (double)p.y[i0] : 0.0;
-    const double Z0 = valid0 ? (double)p.z[i0] : 0.0;
-    const double X1 = valid1 ? (double)p.x[i1] : __builtin_nan("");
-    const double Y1 = valid1 ? (double)p.y[i1] : 0.0;
-    const double Z1 = valid1 ? (double)p.z[i1] : 0.0;
-    const uint8_t* __restrict__ pool = p.pool;
-
-    int best0 = -1, bestc0 = 0, best1 = -1, bestc1 = 0;
-    for (int vb = p.nviews; vb > 0; vb -= U) {  // views vb-1, vb-2, .. (reverse order)
-        int bin0[U], bin1[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb - 1 - u;
-            bin0[u] = bin1[u] = -1;
-            if (v >= 0) {  // wave-uniform
-                const ViewRegs vd = load_view(views + v);
-                const long long off0 = seg_index_regs<DIV>(vd, views + v, X0, Y0, Z0);
-                const long long off1 = seg_index_regs<DIV>(vd, views + v, X1, Y1, Z1);
-                if (off0 >= 0) bin0[u] = pool[off0];
-                if (off1 >= 0) bin1[u] = pool[off1];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (bin0[u] >= 0) {
-                const int c = h0[bin0[u]] + 1;  // dls.py:295
-                h0[bin0[u]] = (uint8_t)c;
-                if (c >= bestc0) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
-                    bestc0 = c;
-                    best0 = bin0[u];
-                }
-            }
-            if (bin1[u] >= 0) {
-                const int c = h1[bin1[u]] + 1;
-                h1[bin1[u]] = (uint8_t)c;
-                if (c >= bestc1) {
-                    bestc1 = c;
-                    best1 = bin1[u];
-                }
-            }
-        }
-    }
-    if (valid0) labels[p.perm ? (long long)p.perm[i0] : i0] = best0 - 1 + (best0 < 0);
-    if (valid1) labels[p.perm ? (long long)p.perm[i1] : i1] = best1 - 1 + (best1 < 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -466,21 +413,22 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
     const double Y = valid ? (double)p.y[i] : 0.0;
     const double Z = valid ? (double)p.z[i] : 0.0;
     const uint8_t* __restrict__ pool = p.pool;
-    for (int vb = p.nviews; vb > 0; vb -= U) {
+    // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
         int bin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int v = vb - 1 - u;
-            bin[u] = -1;
-            if (v >= 0) {
-                const long long off = seg_index<DIV>(views + v, X, Y, Z);
-                if (off >= 0) bin[u] = pool[off];
-            }
+            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (bin[u] >= 0) h[bin[u]] = (uint8_t)(h[bin[u]] + 1);
-    }
+        };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
     // transposed store (see vote_fused_planes_kernel): lane (g, t) packs bin 4*it+g of Gaussians 4t..4t+3
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, t = lane & 15;
@@ -573,9 +521,9 @@ __global__ __launch_bounds__(kBlock) void vote_tie_kernel(FusedParams p, const V
     if (pop >= 2) {
         const double X = (double)p.x[i], Y = (double)p.y[i], Z = (double)p.z[i];
         for (int v = 0; v < p.nviews; ++v) {
-            const long long off = seg_index<kDivCertified>(views + v, X, Y, Z);
-            if (off < 0) continue;
-            const unsigned b = p.pool[off];
+            const int sb = seg_bin<kDivFlat>(views + v, p.pool, X, Y, Z);
+            if (sb < 0) continue;
+            const unsigned b = (unsigned)sb;
             uint32_t word = 0;
 #pragma unroll
             for (int w = 0; w < kCandWords; ++w) word = (b >> 5) == (unsigned)w ? mask[w] : word;
@@ -629,16 +577,14 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
     const double Z = valid ? (double)p.z[i] : 0.0;
     const uint8_t* __restrict__ pool = p.pool;
 
-    for (int vb = p.nviews; vb > 0; vb -= U) {
+    // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
         int bin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int v = vb - 1 - u;
-            bin[u] = -1;
-            if (v >= 0) {
-                const long long off = seg_index<DIV>(views + v, X, Y, Z);
-                if (off >= 0) bin[u] = pool[off];
-            }
+            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
         }
         unsigned old[U];  // one LDS round trip per chunk, repeats of a bin resolved in registers
 #pragma unroll
@@ -653,7 +599,10 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
                 h[bin[u]] = (uint16_t)((cnt << 8) | (unsigned)v);  // reverse order: the last store = the earliest view
             }
         }
-    }
+        };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
     // planes are slab-major: [slab][bin][sn] with slab = i / sn (one slab = one rank's share in the
     // all-to-all exchange; a single slab is the plain [bin][n_pad] layout).  sn is a multiple of the block
     // size, so a workgroup never straddles two slabs.
@@ -804,7 +753,10 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.unit_scale = (vd.wscale == 1.0 && vd.hscale == 1.0 && cam->width <= seg_w && cam->height <= seg_h) ? 1 : 0;
 }
 
-static inline int div_mode(const Ctx* c) { return c->opt_flat_project ? kDivFlat : c->opt_fast_div ? kDivCertified : kDivExact; }
+// call after sync_views(): views_simple describes the staged batch
+static inline int div_mode(const Ctx* c) {
+    return c->opt_flat_project ? (c->views_simple ? kDivFlatSimple : kDivFlat) : c->opt_fast_div ? kDivCertified : kDivExact;
+}
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
 int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy, const float* dz, int64_t n,
@@ -821,10 +773,10 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
-        if (div_mode(c) == kDivFlat)
+        if (c->opt_flat_project)
             hipLaunchKernelGGL(project_kernel<kDivFlat>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
                                dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
-        else if (div_mode(c) == kDivCertified)
+        else if (c->opt_fast_div)
             hipLaunchKernelGGL(project_kernel<kDivCertified>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
                                dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
         else
@@ -900,6 +852,8 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     if (seg_w < 1 || seg_h < 1 || img_w < 1 || img_h < 1)
         return fail(c, GSX_E_INVALID, "vote_view: sizes must be positive (seg %dx%d, image %dx%d)", seg_w, seg_h, img_w,
                     img_h);
+    if (seg_w > 65535 || seg_h > 65535)  // in-map byte offsets are 32-bit, row products use 24-bit multiplies
+        return fail(c, GSX_E_RANGE, "vote_view: segmentation map %dx%d exceeds 65535 pixels a side", seg_w, seg_h);
     if (seg_dtype != GSX_SEG_I32 && seg_dtype != GSX_SEG_I64 && seg_dtype != GSX_SEG_U8)
         return fail(c, GSX_E_INVALID, "vote_view: unknown seg_dtype %d", seg_dtype);
     if (c->first_view + (int)c->views.size() >= c->total_views)
@@ -912,8 +866,11 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     const long long npix = (long long)seg_w * seg_h;
     const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
     const size_t off = (c->seg_used + 255) / 256 * 256;  // 256-B aligned maps
-    const int tiles_w = c->opt_seg_tiled ? (seg_w + 15) / 16 : 0;
-    const size_t map_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_h + 7) / 8) * 128 : (size_t)npix + 4;
+    // "tiled" maps are stored as strips of 16 columns; tiles_w = bytes per strip (rows padded to a multiple of 8)
+    const int tiles_w = c->opt_seg_tiled ? (seg_h + 7) / 8 * 128 : 0;
+    const size_t map_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_w + 15) / 16) : (size_t)npix + 4;
+    if (map_bytes > 0xffffffffull)
+        return fail(c, GSX_E_RANGE, "vote_view: segmentation map %dx%d exceeds 4 GiB", seg_w, seg_h);
     int rc = pool_reserve(c, off + map_bytes);
     if (rc) return rc;
     const void* src = seg;
@@ -948,7 +905,7 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     ViewDesc vd;
     fill_view_desc(vd, cam, seg_w, seg_h, img_w, img_h);
     vd.seg_off = (long long)off;
-    vd.seg_tw = tiles_w;
+    vd.seg_row_bytes = tiles_w;
     c->views.push_back(vd);
     c->views_dirty = true;
     c->seg_used = off + map_bytes;
@@ -960,10 +917,18 @@ static int sync_views(Ctx* c) {
     if (!c->views_dirty) return GSX_OK;
     const size_t bytes = sizeof(ViewDesc) * (c->views.empty() ? 1 : c->views.size());
     GSX_HIP(c, c->d_views.ensure(bytes));
-    if (!c->views.empty())
-        GSX_HIP(c, hipMemcpyAsync(c->d_views.p, c->views.data(), sizeof(ViewDesc) * c->views.size(),
-                                  hipMemcpyHostToDevice, c->stream));
-    GSX_HIP(c, hipStreamSynchronize(c->stream));  // c->views may be reallocated by the next push_back
+    c->views_simple = !c->views.empty();
+    if (!c->views.empty()) {
+        // device copy: seg_off becomes the absolute address of the map (one scalar add less per view and wave)
+        std::vector<ViewDesc> dev(c->views);
+        const long long base = (long long)reinterpret_cast<uintptr_t>(c->segpool.p);
+        for (ViewDesc& v : dev) {
+            v.seg_off += base;
+            c->views_simple = c->views_simple && v.unit_scale && v.seg_row_bytes;
+        }
+        GSX_HIP(c, hipMemcpyAsync(c->d_views.p, dev.data(), sizeof(ViewDesc) * dev.size(), hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));  // `dev` dies here
+    }
     c->views_dirty = false;
     return GSX_OK;
 }
@@ -1057,12 +1022,20 @@ int vote_flush(Ctx* c) {
         const int fresh = (c->planes_zero || c->planes_stale) ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
-            auto k = div_mode(c) == kDivFlat ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
+            const int dm = div_mode(c);
+            auto k = dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatSimple>
+                     : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlat>
+                     : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified>
+                                           : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint16_t>(),
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
-            auto k = div_mode(c) == kDivFlat ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified> : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
+            const int dm = div_mode(c);
+            auto k = dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
+                     : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat>
+                     : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified>
+                                           : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
                                c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
@@ -1149,24 +1122,14 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
 #define GSX_ROW(U_) \
     {{vote_fused_labels_kernel<U_, kDivExact, false>, vote_fused_labels_kernel<U_, kDivExact, true>},         \
      {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
-     {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>}}
-            static const K table[3][3][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
+     {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>},           \
+     {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}}
+            static const K table[3][4][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
 #undef GSX_ROW
-            static const K table2[3][3] = {
-                {vote_fused_labels2_kernel<2, kDivExact>, vote_fused_labels2_kernel<2, kDivCertified>, vote_fused_labels2_kernel<2, kDivFlat>},
-                {vote_fused_labels2_kernel<4, kDivExact>, vote_fused_labels2_kernel<4, kDivCertified>, vote_fused_labels2_kernel<4, kDivFlat>},
-                {vote_fused_labels2_kernel<8, kDivExact>, vote_fused_labels2_kernel<8, kDivCertified>, vote_fused_labels2_kernel<8, kDivFlat>}};
-            static const K table3[3][3] = {
-                {vote_fused_labels_pipe_kernel<2, kDivExact>, vote_fused_labels_pipe_kernel<2, kDivCertified>, vote_fused_labels_pipe_kernel<2, kDivFlat>},
-                {vote_fused_labels_pipe_kernel<4, kDivExact>, vote_fused_labels_pipe_kernel<4, kDivCertified>, vote_fused_labels_pipe_kernel<4, kDivFlat>},
-                {vote_fused_labels_pipe_kernel<8, kDivExact>, vote_fused_labels_pipe_kernel<8, kDivCertified>, vote_fused_labels_pipe_kernel<8, kDivFlat>}};
-            const bool two = c->opt_vote_gpt == 2;
-            const int dm = div_mode(c);
-            K k = c->opt_vote_gpt == 3 ? table3[ui][dm] : two ? table2[ui][dm] : table[ui][dm][c->opt_lds_batch ? 1 : 0];
+            K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
             if ((rc = set_lds(c, k, lds))) return rc;
             ProfScope ps(c, "vote_fused_labels");
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(two ? kBlock2 : kBlock), lds, c->stream, p, p.views,
-                               c->labels.as<int>());
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());
             GSX_HIP(c, hipGetLastError());
         }
         return labels_to_host(c, labels_out);
@@ -1207,7 +1170,11 @@ int vote_flush_counts(Ctx* c) {
     if (c->n > 0) {
         FusedParams p = fused_params(c, 1);
         const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-        auto k = div_mode(c) == kDivFlat ? vote_fused_counts_kernel<kUnroll, kDivFlat> : div_mode(c) == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified> : vote_fused_counts_kernel<kUnroll, kDivExact>;
+        const int dm = div_mode(c);
+        auto k = dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
+                 : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
+                 : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
+                                       : vote_fused_counts_kernel<kUnroll, kDivExact>;
         if ((rc = set_lds(c, k, lds))) return rc;
         ProfScope ps(c, "vote_fused_counts");
         hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),

@@ -73,8 +73,9 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
  *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 2, 4, 8
- *   "vote_gpt"     (default 1)  Gaussians per thread of the single-GPU vote kernel: 1 (256-thread workgroups) or
- *                               2 (128-thread workgroups, two independent chains per lane)
+ *   "flat_project" (default 1)  the projection as one straight-line block (all rows, both divisions, one predicate at
+ *                               the end, one wave-uniform depth early-out) instead of the reference's three early
+ *                               returns as divergent branches; same operations on the same operands
  *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
  *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
  *   "fast_div"     (default 0)  projection through ONE reciprocal with a certified margin; lanes within 2^-20 of a
@@ -89,8 +90,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               diverge (+0.5 ms): off until the binning is wave-cooperative
  *   "tile_lpt"     (default 0)  rasterizer: blend the tiles with the longest splat lists first (measured:
  *                               blend -3 %, paid back by the extra ordering launches)
- *   "seg_tiled"    (default 1)  keep the u8 seg maps as 16x8-pixel tiles of 128 B (applies to the
- *                               views staged after the call) */
+ *   "seg_tiled"    (default 1)  keep the u8 seg maps as strips of 16 pixel columns (16x8 pixels per 128-B line;
+ *                               applies to the views staged after the call) */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
 
 /* ---------------------------------------------------------------------------------------------

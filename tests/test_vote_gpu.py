@@ -76,11 +76,8 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
-                 {"vote_gpt": 2}, {"vote_gpt": 2, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"vote_gpt": 2, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0},
-                 {"flat_project": 1}, {"flat_project": 1, "vote_unroll": 2, "spatial_sort": 0}, {"flat_project": 1, "vote_gpt": 2},
-                 {"vote_gpt": 3}, {"vote_gpt": 3, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"vote_gpt": 3, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}):
+                 {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -413,6 +410,19 @@ def test_errors(ctx, gsx):
         ctx.vote_view(cam, np.full((48, 64), 9, np.int32))        # more views than announced
     with pytest.raises(gsx.GsxError):
         ctx.vote_begin(256, 0, 1)                                  # unsupported class count (u8 maps hold label+1)
+    ctx.vote_begin(10, 0, 2)
+    with pytest.raises(ValueError):
+        ctx.vote_view(cam, np.zeros((1, 65536), np.uint8), image_size=(64, 48))   # a side beyond 65535 pixels
+    wide = np.zeros((2, 65535), np.uint8)                         # the widest supported map: last column is reachable
+    wide[:, -1] = 7
+    far = dict(cam, width=65535, height=2, fx=1.0, fy=1.0, rotation=np.eye(3).tolist(), position=[0.0, 0.0, 0.0])
+    pts = np.array([[32767.25, 0.25, 1.0], [0.0, 0.0, 1.0], [32767.0, -0.75, 1.0]], np.float32)
+    ctx.upload_positions(pts)
+    ctx.vote_begin(10, 0, 1)
+    ctx.vote_view(far, wide)                                       # u8 maps hold label + 1
+    want = oracle.assign_labels(pts, [far], [wide.astype(np.int32) - 1], [(65535, 2)], threads=1)
+    assert want.tolist() == [6, -1, 6] and np.array_equal(ctx.vote_finalize(), want)
+    ctx.upload_positions(np.zeros((10, 3), np.float32))
     ctx.vote_begin(255, 0, 1)                                      # the largest supported one
     ctx.vote_view(cam, np.full((48, 64), 254, np.int32))
     assert (ctx.vote_finalize() == np.where(oracle.project_many(np.zeros((10, 3), np.float32), cam)[0] >= 0, 254, -1)).all()
@@ -456,7 +466,6 @@ def test_randomised_small_configurations(gsx):
             c.set_option("vote_unroll", int(rng.choice([2, 4, 8])))
             c.set_option("lds_batch", int(rng.integers(0, 2)))
             c.set_option("fast_div", int(rng.integers(0, 2)))
-            c.set_option("vote_gpt", int(rng.integers(1, 4)))
             c.set_option("flat_project", int(rng.integers(0, 2)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
