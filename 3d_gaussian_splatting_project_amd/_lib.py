@@ -101,6 +101,8 @@ _SIGS = {
     "gsx_ply_read_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "gsx_ply_set_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "gsx_ply_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]),
+    "gsx_vote_culled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "gsx_debug_cull_planes": (C.c_int, [C.POINTER(Camera), C.c_void_p]),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsx_profile_reset": (C.c_int, [C.c_void_p]),
@@ -125,10 +127,11 @@ def lib():
     """Load libgsx.so.  Raises if it has not been built: the HIP library IS the product."""
     global _lib
     if _lib is None:
-        if not os.path.exists(SO_PATH):
-            raise ImportError(f"{SO_PATH} is missing: build it with `make -C {CSRC}` "
+        path = os.environ.get("GSX_LIBRARY") or SO_PATH   # GSX_LIBRARY: another build of the same C ABI (tools/ablate.sh)
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing: build it with `make -C {CSRC}` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
-        l = C.CDLL(SO_PATH)
+        l = C.CDLL(path)
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res

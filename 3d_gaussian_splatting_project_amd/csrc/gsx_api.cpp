@@ -123,7 +123,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream);
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
-    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->segpool, &c->stage, &c->errflag,
+    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->stage, &c->errflag,
                            &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
@@ -147,7 +147,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     if (!name) return gsx::fail(c, GSX_E_INVALID, "set_option: name is NULL");
     const std::string k(name);
     if (k == "spatial_sort") c->opt_spatial_sort = value != 0;
-    else if (k == "xcd_swizzle") c->opt_xcd_swizzle = value != 0;
+    else if (k == "xcd_swizzle") {
+        if (value < 0 || value > 65536) return gsx::fail(c, GSX_E_INVALID, "set_option: xcd_swizzle must be in [0,65536]");
+        c->opt_xcd_swizzle = (int)value;
+    }
     else if (k == "seg_tiled") c->opt_seg_tiled = value != 0;
     else if (k == "tile_lpt") c->opt_tile_lpt = value != 0;
     else if (k == "exact_cull") c->opt_exact_cull = value != 0;
@@ -159,6 +162,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "fast_div") c->opt_fast_div = value != 0;
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "flat_project") c->opt_flat_project = value != 0;
+    else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)
             return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 2, 4 or 8");
@@ -395,6 +399,18 @@ int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uin
                      uint32_t* bucket_out) {
     CTX_OR_FAIL(ctx);
     return gsx::render_debug(c, buffer_out, order_out, texdata_out, bucket_out);
+}
+
+int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset) {
+    CTX_OR_FAIL(ctx);
+    if (!wave_views) return gsx::fail(c, GSX_E_INVALID, "vote_culled: NULL argument");
+    return gsx::vote_culled(c, wave_views, reset != 0);
+}
+
+int gsx_debug_cull_planes(const gsx_camera* cam, double* out) {
+    if (!cam || !out) return gsx::fail(nullptr, GSX_E_INVALID, "debug_cull_planes: NULL argument");
+    gsx::debug_cull_planes(cam, out);
+    return GSX_OK;
 }
 
 int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits) {

@@ -66,19 +66,18 @@ struct DevBuf {
 
 // ---- per-view descriptor read by the kernels through scalar (wave-uniform) loads ------------------
 struct alignas(64) ViewDesc {
-    // ---- hot part: loaded in ONE batch of scalar loads per view (vote.hip load_view) ----
-    double R[9];       // cameras.json rotation, row-major                         (dls.py:60)
-    double t[3];       // (-R) @ p in the dgemv association of the oracle           (dls.py:66)
-    double fx, fy;     //                                                           (dls.py:54-55)
+    // ---- core, 128 B = two s_load_dwordx16: everything that differs from view to view in an ordinary capture ----
+    double R[9];        // cameras.json rotation, row-major                         (dls.py:60)
+    double t[3];        // (-R) @ p in the dgemv association of the oracle           (dls.py:66)
+    double fx, fy;      //                                                           (dls.py:54-55)
+    long long seg_off;  // host copy: byte offset of this view's u8 map in the seg pool; device copy
+                        // (sync_views): the map's absolute address
+    int seg_row_bytes;  // bytes per strip of 16 pixel columns (0: row-major map)
+    int unit_scale;     // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
+    // ---- frame, 48 B: identical for all views when the cameras share one resolution (then kernel constants) ----
     double half_w, half_h;  // width/2, height/2                                    (dls.py:76-77)
     double width, height;   // bounds of the visibility test                        (dls.py:80)
-    long long seg_off;      // host copy: byte offset of this view's u8 map in the seg pool; device copy
-                            // (sync_views): the map's absolute address
-    int seg_w;
-    int unit_scale;  // both scales are exactly 1.0 and the camera frame fits the map: skip scale + clamp
-    // ---- 16 more hot bytes ----
-    int seg_row_bytes;  // bytes per strip of 16 pixel columns (0: row-major map)
-    int seg_h;          // (cold: scale + clamp path only)
+    int seg_w, seg_h;
     int cam_w, cam_h;   // camera width / height as integers (visibility test of the certified path)
     int pad_[4];
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
@@ -106,7 +105,7 @@ struct Ctx {
 
     // options (gsx_set_option)
     int opt_spatial_sort = 1;  // Morton-order the Gaussians at upload (results do not depend on it)
-    int opt_xcd_swizzle = 1;   // consecutive logical workgroups share an XCD (its L2)
+    int opt_xcd_swizzle = 16;  // 0: off, 1: contiguous eighths of the Morton curve per XCD, C: chunks of C workgroups round-robin
     int opt_vote_unroll = 8;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
     int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
     int opt_local_codes = 0;   // see Ctx::local_codes
@@ -127,6 +126,10 @@ struct Ctx {
     int slabs = 1;             // planes are [slab][bins][sn]; one slab per rank of the all-to-all exchange
     int64_t sn = 0;            // Gaussians per slab (multiple of 256); n_pad = slabs * sn
     std::vector<ViewDesc> views;
+    DevBuf d_cull;               // double[25][cull_pitch]: five world-space culling planes per staged view
+    int cull_pitch = 0;
+    DevBuf d_cull_tally;         // u64: (wave, view) pairs skipped by the culling since the last reset
+    int opt_wave_cull = 0;       // skip (wave, view) pairs whose 64 Gaussians provably all miss the frame (measured: no gain)
     bool views_dirty = true;  // host views newer than d_views
     bool views_simple = false;  // every staged view: unit scale + tiled map (set by sync_views)
     DevBuf d_views;
@@ -200,6 +203,8 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
 int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
                      int* result_in);
 int spatial_sort_positions(Ctx* c);
+int vote_culled(Ctx* c, int64_t* out, bool reset);
+void debug_cull_planes(const gsx_camera* cam, double* out);
 // render.hip
 int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const float* rot, const float* opacity,
                   const float* f_dc, const int32_t* labels);

@@ -17,6 +17,9 @@
 
 #include <algorithm>
 
+#include <cmath>
+#include <algorithm>
+
 #include "gsx_ctx.hpp"
 
 namespace gsx {

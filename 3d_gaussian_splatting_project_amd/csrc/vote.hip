@@ -36,6 +36,10 @@
 
 #include <type_traits>
 
+#ifndef GSX_ABLATE
+#define GSX_ABLATE 0  // product build; tools/ablate.sh builds timing-only variants (results invalid)
+#endif
+
 #include "gsx_ctx.hpp"
 
 namespace gsx {
@@ -70,11 +74,24 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // fields below are sub-registers of those tuples, no scalar move is spent on them.  (Pinning the 24 fields one
 // by one cost 15 s_mov per view; the scalar unit is shared by the four SIMDs of a CU and every wave issues at
 // most one instruction per turn, so scalar bookkeeping was costing as much as the fp64 arithmetic.)
+__device__ __forceinline__ void unpack_core(ViewRegs& r, const v16i& a, const v16i& b) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r.R[k] = chunk_f64(a, k);
+    r.R[8] = chunk_f64(b, 0);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.t[k] = chunk_f64(b, 1 + k);
+    r.fx = chunk_f64(b, 4);
+    r.fy = chunk_f64(b, 5);
+    r.seg_off = __builtin_bit_cast(long long, chunk_f64(b, 6));
+    r.seg_row_bytes = b[14];
+    r.unit_scale = b[15];
+}
+
 __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
     static_assert(offsetof(ViewDesc, R) == 0 && offsetof(ViewDesc, t) == 72 && offsetof(ViewDesc, fx) == 96 &&
-                      offsetof(ViewDesc, half_w) == 112 && offsetof(ViewDesc, width) == 128 &&
-                      offsetof(ViewDesc, seg_off) == 144 && offsetof(ViewDesc, seg_w) == 152 &&
-                      offsetof(ViewDesc, unit_scale) == 156 && offsetof(ViewDesc, seg_row_bytes) == 160 &&
+                      offsetof(ViewDesc, seg_off) == 112 && offsetof(ViewDesc, seg_row_bytes) == 120 &&
+                      offsetof(ViewDesc, unit_scale) == 124 && offsetof(ViewDesc, half_w) == 128 &&
+                      offsetof(ViewDesc, width) == 144 && offsetof(ViewDesc, seg_w) == 160 &&
                       offsetof(ViewDesc, cam_w) == 168 && sizeof(ViewDesc) % 64 == 0,
                   "load_view reads the hot part of ViewDesc as 64 + 64 + 32 + 16 bytes");
     const char* q = reinterpret_cast<const char*>(vp);
@@ -84,29 +101,22 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
     v4i d = *reinterpret_cast<const v4i*>(q + 160);
     asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
     ViewRegs r;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r.R[k] = chunk_f64(a, k);
-    r.R[8] = chunk_f64(b, 0);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) r.t[k] = chunk_f64(b, 1 + k);
-    r.fx = chunk_f64(b, 4);
-    r.fy = chunk_f64(b, 5);
-    r.half_w = chunk_f64(b, 6);
-    r.half_h = chunk_f64(b, 7);
+    unpack_core(r, a, b);
     v2i t;
     t.x = c[0], t.y = c[1];
-    r.width = __builtin_bit_cast(double, t);
+    r.half_w = __builtin_bit_cast(double, t);
     t.x = c[2], t.y = c[3];
-    r.height = __builtin_bit_cast(double, t);
+    r.half_h = __builtin_bit_cast(double, t);
     t.x = c[4], t.y = c[5];
-    r.seg_off = __builtin_bit_cast(long long, t);
-    r.seg_w = c[6];
-    r.unit_scale = c[7];
-    r.seg_row_bytes = d[0];
+    r.width = __builtin_bit_cast(double, t);
+    t.x = c[6], t.y = c[7];
+    r.height = __builtin_bit_cast(double, t);
+    r.seg_w = d[0];
     r.cam_w = d[2];
     r.cam_h = d[3];
     return r;
 }
+
 
 // OpenBLAS dgemv association of `R @ v` for a C-contiguous 3x3 (oracle/vote_oracle.c, header)
 __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1, double v2) {
@@ -226,6 +236,10 @@ __device__ __forceinline__ int seg_bin_regs(const ViewRegs& vd, const ViewDesc* 
             xi = xs > (double)(vd.seg_w - 1) ? vd.seg_w - 1 : (int)xs;  // :285 (xs >= 0 always)
             yi = ys > (double)(seg_h - 1) ? seg_h - 1 : (int)ys;        // :286
         }
+#if GSX_ABLATE & 32  // timing experiment only: the footprint of a 4x4-coarsened map (upper bound for a coarse level)
+        xi >>= 2;
+        yi >>= 2;
+#endif
         unsigned off;
         if (kSimple || vd.seg_row_bytes) {
             // strips of 16 pixel columns, rows of a strip back to back (16 B each): any 8 consecutive rows of a strip
@@ -238,7 +252,15 @@ __device__ __forceinline__ int seg_bin_regs(const ViewRegs& vd, const ViewDesc* 
         // the device copy of the descriptor holds the map's absolute address; say "global" explicitly, a pointer made
         // from an integer would otherwise be a FLAT one (flat loads also count in lgkmcnt and stall the scalar waits)
         typedef const __attribute__((address_space(1))) uint8_t* global_u8;
+#if GSX_ABLATE & 2  // timing experiment only (tools/ablate.sh): no gather, a bin made from the offset
+        bin = (int)(off & 127u);
+#elif GSX_ABLATE & 8  // timing experiment only: every gather falls into the first KiB of the map (always cached)
+        bin = ((global_u8)(unsigned long long)vd.seg_off)[off & 1023u];
+#elif GSX_ABLATE & 16  // timing experiment only: the first 64 KiB of the map (L2-resident, rarely in L1)
+        bin = ((global_u8)(unsigned long long)vd.seg_off)[off & 65535u];
+#else
         bin = ((global_u8)(unsigned long long)vd.seg_off)[off];
+#endif
     }
     return bin;
 }
@@ -267,12 +289,20 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict
 }
 
 // Workgroups b and b+8 run on the same XCD (round-robin dispatch; a speed heuristic, never needed for
-// correctness).  Map them to consecutive logical blocks so that one XCD's L2 serves one contiguous
-// stretch of the Morton curve = one compact patch of every segmentation map.  Bijective for any grid.
+// correctness).  swizzle == 1: XCD x takes the x-th contiguous eighth of the Morton curve.  swizzle == C >= 2: the
+// curve is cut into chunks of C workgroups and chunk k goes to XCD k % 8: an XCD still works on compact pieces
+// of space (its L2 serves compact patches of every segmentation map), but every XCD sees every part of the scene, so
+// the eight of them finish together even when visibility differs from one region to the next.  Bijective for any grid.
 __device__ __forceinline__ unsigned logical_block(unsigned b, unsigned nwg, int swizzle) {
     if (!swizzle) return b;
-    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    if (swizzle == 1) {
+        const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    const unsigned C = (unsigned)swizzle, super = 8u * C;
+    if (b >= nwg / super * super) return b;  // the ragged tail keeps its order
+    const unsigned j = b >> 3;
+    return (j / C) * super + (b & 7u) * C + j % C;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -324,16 +354,114 @@ struct FusedParams {
     int stride_dw;         // LDS row stride in dwords (odd)
     int xcd_swizzle;       // see logical_block()
     const uint32_t* perm;  // sorted slot -> caller's index, or nullptr
+    const double* cull;    // culling planes of the batch's views, [25][cull_pitch] (nullptr: no culling)
+    int cull_pitch;
+    unsigned long long* cull_tally;  // [0] += (wave, view) pairs skipped
 };
+
+// ---- wave-level view culling ------------------------------------------------------------------------------------
+// 40 % of the (Gaussian, view) pairs of an ordinary capture are invisible, and in Morton order they come in whole
+// waves.  Each wave bounds its 64 Gaussians by a sphere (c, r) once; then LANE l tests view l against the five
+// world-space planes the host derived from that view's frustum (gsx::cull_planes): a plane is stored as a unit normal
+// A, an offset B and a margin slope M, and `A.c + B > r + M (|c|_1 + r)` proves that every point of the sphere fails the reference's visibility test (dls.py:72, :80) by more than a million times the rounding error of
+// the fp64 projection.  One ballot turns 64 such tests into a 64-bit mask; a culled view costs two scalar
+// instructions instead of ~50 fp64 ones, and no descriptor load.  Bits are indexed by the REVERSE view index
+// (nviews-1-v), so that the U views of a chunk are U adjacent bits.  Pairs that are not provably invisible take
+// the exact path as before: the result is unchanged, bit for bit.
+static constexpr int kCullPlanes = 5;
+struct CullMasks {
+    unsigned long long m[4];  // kMaxBatch <= 256 views
+};
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+
+// X is NaN on lanes past the end of the scene: fmin / fmax ignore them (and NaN positions, which never vote).
+__device__ __forceinline__ CullMasks wave_cull_masks(const double* __restrict__ cull, int pitch, int nviews, double X,
+                                                     double Y, double Z, unsigned long long* __restrict__ tally) {
+    CullMasks k;
+    k.m[0] = k.m[1] = k.m[2] = k.m[3] = 0;
+    if (!cull) return k;  // wave-uniform
+    const double big = 1.7e308;
+    const double lx = wave_min(X == X ? X : big), hx = wave_max(X == X ? X : -big);
+    const double ly = wave_min(X == X ? Y : big), hy = wave_max(X == X ? Y : -big);
+    const double lz = wave_min(X == X ? Z : big), hz = wave_max(X == X ? Z : -big);
+    const double cx = 0.5 * lx + 0.5 * hx, cy = 0.5 * ly + 0.5 * hy, cz = 0.5 * lz + 0.5 * hz;
+    const double dx = X - cx, dy = Y - cy, dz = Z - cz;
+    // r >= the distance of every member from c; the factor covers the rounding of the distance itself.
+    // An infinite coordinate makes c or r non-finite and every test below false: such a wave is never culled.
+    const double r = wave_max(sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-12);
+    const double reach = fabs(cx) + fabs(cy) + fabs(cz) + r;  // >= |p| for every member: scales the rounding margin
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (64 * j < nviews) {  // wave-uniform
+            const int ri = 64 * j + lane;  // reverse view index
+            bool out = false;
+            if (ri < nviews) {
+                const double* q = cull + (nviews - 1 - ri);
+#pragma unroll
+                for (int pl = 0; pl < kCullPlanes; ++pl) {
+                    const double a0 = q[(5 * pl + 0) * pitch], a1 = q[(5 * pl + 1) * pitch], a2 = q[(5 * pl + 2) * pitch];
+                    const double b = q[(5 * pl + 3) * pitch], m = q[(5 * pl + 4) * pitch];
+                    out = out | (a0 * cx + a1 * cy + a2 * cz + b > r + m * reach);
+                }
+            }
+            k.m[j] = __builtin_amdgcn_ballot_w64(out);
+        }
+    }
+    if (tally && lane == 0)  // statistics for gsx_vote_culled(): one atomic per wave
+        atomicAdd(tally, (unsigned long long)(__popcll(k.m[0]) + __popcll(k.m[1]) + __popcll(k.m[2]) + __popcll(k.m[3])));
+    return k;
+}
+
+// the U bits of the chunk that starts `done` views into the (reverse) walk; 64 % U == 0, so they share a word
+template <int U>
+__device__ __forceinline__ unsigned cull_bits(const CullMasks& k, int done) {
+    const int w = done >> 6;
+    const unsigned long long word = w == 0 ? k.m[0] : w == 1 ? k.m[1] : w == 2 ? k.m[2] : k.m[3];
+    return (unsigned)(word >> (done & 63)) & ((1u << U) - 1u);
+}
+
+// One chunk of U views (vb-1, vb-2, ..): bin[u] = the vote of this lane's Gaussian in view vb-1-u, or -1.
+// FULL: all U views exist (no index test).  culled: bit u set = the whole wave provably misses view vb-1-u.
+template <int U, int DIV, bool FULL>
+__device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views, const uint8_t* __restrict__ pool, int vb,
+                                             double X, double Y, double Z, unsigned culled, int (&bin)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int v = vb - 1 - u;  // `v >= 0` is wave-uniform
+        if ((culled >> u) & 1u) {  // wave-uniform
+            bin[u] = -1;
+            continue;
+        }
+#if GSX_ABLATE & 4  // timing experiment only: ONE descriptor for all views (no scalar loads in the loop; NOTE: every
+                    // view then votes the same pixel, so the gathers become free as well); the view-dependent
+                    // perturbation (it rounds away) keeps the arithmetic inside the loop
+        const ViewRegs vd0 = load_view(views);
+        bin[u] = (FULL || v >= 0) ? seg_bin_regs<DIV>(vd0, views, pool, __builtin_fma((double)v, 1e-300, X), Y, Z) : -1;
+#else
+        bin[u] = (FULL || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;
+#endif
+    }
+}
 
 template <int U, int DIV, bool LDS_BATCH>
 __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
     uint32_t* row = lds + threadIdx.x * p.stride_dw;
-    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
     uint8_t* h = reinterpret_cast<uint8_t*>(row);
 
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
     const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     const bool valid = i < p.n;
     // lanes past the end carry NaN: every comparison in project() fails, they never vote
@@ -344,15 +472,17 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 
     int best = -1;  // bin of the current winner
     int bestc = 0;
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
     // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+#if GSX_ABLATE & 1  // timing experiment only: no LDS histogram, the bins are just consumed
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb - 1 - u;
-            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
-        }
+        for (int u = 0; u < U; ++u) best += bin[u];
+        if (false)
+#endif
         if (LDS_BATCH) {
             // one LDS round trip for the whole chunk: read the U counters first, resolve repeats of a bin
             // inside the chunk in registers, then apply the votes in (reverse view) order
@@ -413,15 +543,12 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
     const double Y = valid ? (double)p.y[i] : 0.0;
     const double Z = valid ? (double)p.z[i] : 0.0;
     const uint8_t* __restrict__ pool = p.pool;
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
     // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb - 1 - u;
-            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
-        }
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (bin[u] >= 0) h[bin[u]] = (uint8_t)(h[bin[u]] + 1);
@@ -577,15 +704,12 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
     const double Z = valid ? (double)p.z[i] : 0.0;
     const uint8_t* __restrict__ pool = p.pool;
 
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
     // views vb-1, vb-2, .. (reverse order); only the last, ragged chunk tests its view indices
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb - 1 - u;
-            bin[u] = (kFull || v >= 0) ? seg_bin<DIV>(views + v, pool, X, Y, Z) : -1;  // `v >= 0` is wave-uniform
-        }
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
         unsigned old[U];  // one LDS round trip per chunk, repeats of a bin resolved in registers
 #pragma unroll
         for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (unsigned)h[bin[u]] : 0u;
@@ -755,7 +879,8 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
 
 // call after sync_views(): views_simple describes the staged batch
 static inline int div_mode(const Ctx* c) {
-    return c->opt_flat_project ? (c->views_simple ? kDivFlatSimple : kDivFlat) : c->opt_fast_div ? kDivCertified : kDivExact;
+    if (!c->opt_flat_project) return c->opt_fast_div ? kDivCertified : kDivExact;
+    return c->views_simple ? kDivFlatSimple : kDivFlat;
 }
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
@@ -913,6 +1038,72 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     return GSX_OK;
 }
 
+// Five world-space planes per view for wave_cull_masks().  With pc = R p + t (camera space) the reference rejects a
+// Gaussian when pc_z <= 0 (dls.py:72) or when px = fx pc_x / pc_z + w/2 leaves [0, w) (:80), i.e. for pc_z > 0 when
+// h(pc) >= 0 for one of
+//      h = -pc_z,   fx pc_x - (w/2) pc_z,   -fx pc_x - (w/2) pc_z,   fy pc_y - (h/2) pc_z,   -fy pc_y - (h/2) pc_z .
+// Each h = alpha . pc = (R^T alpha) . p + alpha . t is linear in the world position p; over a sphere (c, r) its minimum
+// is a.c + b - r |a|.  The floating-point projection of a point p can deviate from real arithmetic by at most a few
+// ulp of |alpha|_1 (|R|_F |p| + |t|), so the test demands h >= delta with delta = 1e-9 times that quantity (a million
+// times the worst case) for the largest |p| of the sphere: stored are A = a/|a|, B = (b - 1e-9 |alpha|_1 |t|)/|a|
+// and M = 1e-9 |alpha|_1 |R|_F / |a|, and the device tests  A.c + B > r + M (|c|_1 + r).
+// Views with non-finite or extreme parameters (outside 1e-30 .. 1e30) get planes that never fire.
+static constexpr int kCullStride = 5;  // doubles per plane
+static void cull_planes(const ViewDesc& v, double out[kCullStride * kCullPlanes]) {
+    for (int k = 0; k < kCullPlanes; ++k) {  // "never": 0.c - 1 > r + 0 is false for every r >= 0
+        for (int j = 0; j < kCullStride; ++j) out[kCullStride * k + j] = 0.0;
+        out[kCullStride * k + 3] = -1.0;
+    }
+    double rf = 0.0, tn = 0.0;
+    for (int k = 0; k < 9; ++k) rf += v.R[k] * v.R[k];
+    for (int k = 0; k < 3; ++k) tn += v.t[k] * v.t[k];
+    rf = std::sqrt(rf);
+    tn = std::sqrt(tn);
+    auto sane = [](double x, double lo) { return std::isfinite(x) && std::fabs(x) >= lo && std::fabs(x) <= 1e30; };
+    if (!(sane(rf, 1e-10) && sane(tn, 0.0) && sane(v.fx, 1e-30) && sane(v.fy, 1e-30) && sane(v.half_w, 1e-30) &&
+          sane(v.half_h, 1e-30) && rf <= 1e10))
+        return;
+    const double alpha[kCullPlanes][3] = {{0.0, 0.0, -1.0},
+                                          {v.fx, 0.0, -v.half_w},
+                                          {-v.fx, 0.0, -v.half_w},
+                                          {0.0, v.fy, -v.half_h},
+                                          {0.0, -v.fy, -v.half_h}};
+    for (int k = 0; k < kCullPlanes; ++k) {
+        const double* al = alpha[k];
+        double a[3], b = 0.0, l1 = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            a[j] = v.R[0 + j] * al[0] + v.R[3 + j] * al[1] + v.R[6 + j] * al[2];  // (R^T alpha)_j
+            b += al[j] * v.t[j];
+            l1 += std::fabs(al[j]);
+        }
+        const double na = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        if (!(std::isfinite(na) && na > 1e-200 && std::isfinite(b))) continue;
+        double pl[kCullStride] = {a[0] / na, a[1] / na, a[2] / na, (b - 1e-9 * l1 * tn - 1e-280) / na, 1e-9 * l1 * rf / na};
+        bool ok = true;
+        for (int j = 0; j < kCullStride; ++j) ok = ok && std::isfinite(pl[j]);
+        if (ok)
+            for (int j = 0; j < kCullStride; ++j) out[kCullStride * k + j] = pl[j];
+    }
+}
+
+int vote_culled(Ctx* c, int64_t* out, bool reset) {
+    unsigned long long h = 0;
+    if (c->d_cull_tally.p) {
+        GSX_HIP(c, hipSetDevice(c->device));
+        GSX_HIP(c, hipMemcpyAsync(&h, c->d_cull_tally.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+        if (reset) GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof h, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *out = (int64_t)h;
+    return GSX_OK;
+}
+
+void debug_cull_planes(const gsx_camera* cam, double* out) {
+    ViewDesc vd;
+    fill_view_desc(vd, cam, cam->width > 0 ? cam->width : 1, cam->height > 0 ? cam->height : 1, 1, 1);
+    cull_planes(vd, out);
+}
+
 static int sync_views(Ctx* c) {
     if (!c->views_dirty) return GSX_OK;
     const size_t bytes = sizeof(ViewDesc) * (c->views.empty() ? 1 : c->views.size());
@@ -927,7 +1118,22 @@ static int sync_views(Ctx* c) {
             c->views_simple = c->views_simple && v.unit_scale && v.seg_row_bytes;
         }
         GSX_HIP(c, hipMemcpyAsync(c->d_views.p, dev.data(), sizeof(ViewDesc) * dev.size(), hipMemcpyHostToDevice, c->stream));
-        GSX_HIP(c, hipStreamSynchronize(c->stream));  // `dev` dies here
+        // culling planes, plane-component-major so that lane l reads view l with unit stride
+        const int pitch = (int)((dev.size() + 63) / 64 * 64);
+        std::vector<double> planes((size_t)kCullStride * kCullPlanes * pitch, 0.0);
+        for (size_t i = 0; i < dev.size(); ++i) {
+            double pl[kCullStride * kCullPlanes];
+            cull_planes(dev[i], pl);
+            for (int k = 0; k < kCullStride * kCullPlanes; ++k) planes[(size_t)k * pitch + i] = pl[k];
+        }
+        GSX_HIP(c, c->d_cull.ensure(sizeof(double) * planes.size()));
+        GSX_HIP(c, hipMemcpyAsync(c->d_cull.p, planes.data(), sizeof(double) * planes.size(), hipMemcpyHostToDevice, c->stream));
+        c->cull_pitch = pitch;
+        if (!c->d_cull_tally.p) {
+            GSX_HIP(c, c->d_cull_tally.ensure(sizeof(unsigned long long)));
+            GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof(unsigned long long), c->stream));
+        }
+        GSX_HIP(c, hipStreamSynchronize(c->stream));  // `dev` and `planes` die here
     }
     c->views_dirty = false;
     return GSX_OK;
@@ -1018,6 +1224,9 @@ int vote_flush(Ctx* c) {
         const int batch = std::min(kMaxBatch, nv - c->n_flushed);
         p.views = c->d_views.as<ViewDesc>() + c->n_flushed;
         p.nviews = batch;
+        p.cull = c->opt_wave_cull ? c->d_cull.as<double>() + c->n_flushed : nullptr;
+        p.cull_pitch = c->cull_pitch;
+        p.cull_tally = c->d_cull_tally.as<unsigned long long>();
         const int view_base = c->first_view + c->n_flushed;
         const int fresh = (c->planes_zero || c->planes_stale) ? 1 : 0;
         ProfScope ps(c, "vote_fused_planes");
@@ -1115,7 +1324,10 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
             p.xcd_swizzle = c->opt_xcd_swizzle;
             p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
             p.stride_dw = odd_dwords(c->bins);
-            const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+            p.cull = c->opt_wave_cull ? c->d_cull.as<double>() : nullptr;
+            p.cull_pitch = c->cull_pitch;
+            p.cull_tally = c->d_cull_tally.as<unsigned long long>();
+                    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
             // kernel variants: unroll U in {2,4,8} x division mode x batched LDS reads
             using K = void (*)(FusedParams, const ViewDesc*, int*);
             const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
@@ -1154,6 +1366,9 @@ static FusedParams fused_params(Ctx* c, int stride_bytes_per_bin) {
     p.xcd_swizzle = c->opt_xcd_swizzle;
     p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
     p.stride_dw = odd_dwords(c->bins * stride_bytes_per_bin);
+    p.cull = c->opt_wave_cull ? c->d_cull.as<double>() : nullptr;
+    p.cull_pitch = c->cull_pitch;
+    p.cull_tally = c->d_cull_tally.as<unsigned long long>();
     return p;
 }
 

@@ -191,6 +191,12 @@ class Context:
               self.h)
         return out
 
+    def vote_culled(self, reset=False):
+        """(wave, view) pairs skipped by the wave culling so far (gsx_vote_culled)."""
+        out = C.c_int64(0)
+        check(self._lib.gsx_vote_culled(self.h, C.byref(out), 1 if reset else 0), self.h)
+        return int(out.value)
+
     def debug_planes(self, bins):
         cnt = np.empty((bins, self.n), np.uint16)
         fv = np.empty((bins, self.n), np.uint16)
@@ -286,6 +292,15 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         check(self._lib.gsx_profile_get(self.h, name.encode(), C.byref(n), C.byref(ms)), self.h)
         return n.value, ms.value
+
+
+def cull_planes(camera):
+    """The five world-space culling planes of one view (test hook, host only): array (5, 5) = unit normal A, offset B,
+    margin slope M; a sphere (c, r) is skipped when A.c + B > r + M * (|c|_1 + r) for one of them."""
+    cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
+    out = np.empty((5, 5), np.float64)
+    check(_lib.lib().gsx_debug_cull_planes(C.byref(cam), out.ctypes.data))
+    return out
 
 
 def project_gaussian(position, camera, ctx=None):

@@ -182,6 +182,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    ctx.vote_culled(reset=True)
     if not args.no_profile:
         ctx.profile(True)
     t0 = time.perf_counter()
@@ -195,6 +196,8 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     value = n * total_views / (elapsed / args.steps)
+    # share of the (wave of 64 Gaussians, view) pairs the kernels skipped as provably invisible (wave culling)
+    culled_frac = ctx.vote_culled() / (args.steps * ((n + 63) // 64) * V) if n and V else 0.0
 
     # ---- dominant kernel: HIP-event time on the ctx stream, algorithmic bytes / time ------------------
     kname = "vote_fused_labels" if (world == 1 and not args.force_exchange_path) else ("vote_fused_counts" if use_sparse else "vote_fused_planes")
@@ -278,6 +281,7 @@ def main():
                                                             "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"),
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
+                       "wave_views_culled_fraction": round(culled_frac, 4),
                        "setup_seconds": round(setup_s, 1),
                        "host_map_ingest_ms_per_view": round(ingest_s / max(1, V) * 1e3, 3),
                        "pcie_inclusive_value": round(n * total_views / (ingest_s + elapsed / args.steps), 1) if world == 1 else None},

@@ -71,11 +71,19 @@ int gsx_synchronize(gsx_ctx* ctx);
 /* tuning knobs; none of them changes any result.
  *   "spatial_sort" (default 1)  Morton-order the Gaussians on the GPU at upload: a wave's 64 Gaussians
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
- *   "xcd_swizzle"  (default 1)  consecutive workgroups of the vote kernel share an XCD and its L2
+ *   "xcd_swizzle"  (default 16) which workgroups of the vote kernels share an XCD and its L2: 0 = hardware order,
+ *                               1 = XCD x takes the x-th contiguous eighth of the Morton curve, C >= 2 = the curve
+ *                               is cut into chunks of C workgroups dealt round-robin to the XCDs (compact pieces
+ *                               of space per L2, and all XCDs finish together)
  *   "vote_unroll"  (default 8)  views whose seg-map gathers are in flight together: 2, 4, 8
  *   "flat_project" (default 1)  the projection as one straight-line block (all rows, both divisions, one predicate at
  *                               the end, one wave-uniform depth early-out) instead of the reference's three early
  *                               returns as divergent branches; same operations on the same operands
+ *   "wave_cull"    (default 0)  skip a view for a whole wave when the bounding sphere of its 64 Gaussians lies
+ *                               outside the view's frustum by a safety margin (see gsx_debug_cull_planes).  Skips
+ *                               33 % of the (wave, view) pairs of the benchmark scene, bit-identical results, but
+ *                               measured 3-5 % SLOWER: the kernel waits on seg-map gathers (which invisible pairs
+ *                               never issued), not on arithmetic
  *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
  *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
  *   "fast_div"     (default 0)  projection through ONE reciprocal with a certified margin; lanes within 2^-20 of a
@@ -275,6 +283,14 @@ int gsx_ply_write(const gsx_ply* ply, const char* path, const int32_t* labels, i
  * which restates the stable counting sort of gs.js:443-457.  Host arrays, sorted in place.
  * ------------------------------------------------------------------------------------------- */
 int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits);
+/* statistics: (wave of 64 Gaussians, view) pairs the vote kernels skipped through the wave culling since the context
+ * was created or since the last call with reset != 0 */
+int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);
+/* test hook, host only (no context, no GPU): the five world-space culling planes the vote kernels use to skip whole
+ * waves for a view (option "wave_cull"), as out[5][5] = unit normal A, offset B, margin slope M: a sphere (c, r) with
+ * A.c + B > r + M (|c|_1 + r) holds no Gaussian that project_gaussian (deep_learning_segmentation.py:43-82) would
+ * accept (the margin is a million times the rounding error of the fp64 projection of any point of the sphere). */
+int gsx_debug_cull_planes(const gsx_camera* cam, double* out);
 
 /* ---------------------------------------------------------------------------------------------
  * profiling hooks (HIP events on the ctx stream around each kernel launch)

@@ -77,7 +77,8 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
                  {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}):
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0},
+                 {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -206,6 +207,39 @@ def test_planes_content_vs_recount(ctx):
     cnt, fv = ctx.debug_planes(151)
     sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 3, 40)
     assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
+
+
+def test_wave_culling_changes_no_vote(gsx):
+    """Every single vote (count plane AND first-view plane) is the same with the wave culling on and off, on a scene
+    where 40 % of the (Gaussian, view) pairs are invisible; labels of all three kernel families agree as well."""
+    n = 400_000
+    V = 24
+    pos, cams, segs = scene.make_scene(n, V, 640, 360, config_id=9, convention="w2c")
+    pos[1000:1064] = np.float32(np.inf)                       # one whole wave of non-finite positions (input order)
+    pos[5000] = np.float32(np.nan)
+    pos[7000:7003] = [[np.inf, 0, 0], [0, -np.inf, 0], [40.0, 55.0, -70.0]]  # (a 1e38 outlier would flatten the Morton grid)
+    sizes = [(640, 360)] * V
+    got = {}
+    for cull in (1, 0):
+        with gsx.Context(0) as c:
+            c.set_option("wave_cull", cull)
+            labels = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+            skipped = c.vote_culled(reset=True) / (((n + 63) // 64) * V)
+            assert (0.15 < skipped < 0.6) if cull else skipped == 0, skipped   # the culling does fire, and only when on
+            c.vote_rewind()
+            c.vote_flush()
+            cnt, fv = c.debug_planes(151)
+            c.vote_tiebreak_keys()
+            assert np.array_equal(c.vote_labels_from_keys(), labels)
+            got[cull] = (labels, cnt, fv)
+    assert np.array_equal(got[1][0], got[0][0])
+    assert np.array_equal(got[1][1], got[0][1]) and np.array_equal(got[1][2], got[0][2])
+    votes = got[0][1].astype(np.int64).sum(0)
+    assert 0.3 < (votes.sum() / (n * V)) < 0.9               # a good share of the pairs is invisible
+    sample = np.random.default_rng(2).choice(n, 20_000, replace=False)
+    sample[:80] = list(range(990, 1070))                      # include the non-finite wave
+    want = oracle.assign_labels(np.ascontiguousarray(pos[sample]), cams, segs, sizes, threads=0)
+    assert np.array_equal(got[1][0][sample], want)
 
 
 def test_wide_counters_and_multi_batch(ctx):
@@ -467,6 +501,7 @@ def test_randomised_small_configurations(gsx):
             c.set_option("lds_batch", int(rng.integers(0, 2)))
             c.set_option("fast_div", int(rng.integers(0, 2)))
             c.set_option("flat_project", int(rng.integers(0, 2)))
+            c.set_option("wave_cull", int(rng.integers(0, 2)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
             for v in range(V):

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build timing-only variants of libgsx.so with parts of the vote kernel removed (GSX_ABLATE bit mask:
+# 1 = no LDS histogram, 2 = no seg-map gather, 4 = no per-view scalar loads).  RESULTS ARE INVALID by design;
+# the variants only answer "where does the time go".  Run here (build container); bench them on the GPU box with
+#   GSX_LIBRARY=tools/ablate/libgsx_<mask>.so python bench.py --cpu-sample 0 --render-views 0 --no-verify
+set -e
+cd "$(dirname "$0")/../3d_gaussian_splatting_project_amd/csrc"
+make >/dev/null
+mkdir -p ../../tools/ablate
+for m in 2 32; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-result --offload-arch=gfx950 -ffp-contract=off -DGSX_ABLATE=$m -c vote.hip -o /tmp/vote_ablate_$m.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/libgsx_$m.so gsx_api.o /tmp/vote_ablate_$m.o sort.o render.o blend.o ply_io.o
+done
+ls -la ../../tools/ablate
