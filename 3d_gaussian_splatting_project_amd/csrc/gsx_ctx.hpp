@@ -105,7 +105,7 @@ struct Ctx {
 
     // options (gsx_set_option)
     int opt_spatial_sort = 1;  // Morton-order the Gaussians at upload (results do not depend on it)
-    int opt_xcd_swizzle = 16;  // 0: off, 1: contiguous eighths of the Morton curve per XCD, C: chunks of C workgroups round-robin
+    int opt_xcd_swizzle = 32;  // 0: off, 1: contiguous eighths of the Morton curve per XCD, C: chunks of C workgroups round-robin
     int opt_vote_unroll = 8;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
     int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
     int opt_local_codes = 0;   // see Ctx::local_codes

@@ -71,7 +71,7 @@ int gsx_synchronize(gsx_ctx* ctx);
 /* tuning knobs; none of them changes any result.
  *   "spatial_sort" (default 1)  Morton-order the Gaussians on the GPU at upload: a wave's 64 Gaussians
  *                               then project to neighbouring pixels (seg-map gathers hit few lines)
- *   "xcd_swizzle"  (default 16) which workgroups of the vote kernels share an XCD and its L2: 0 = hardware order,
+ *   "xcd_swizzle"  (default 32) which workgroups of the vote kernels share an XCD and its L2: 0 = hardware order,
  *                               1 = XCD x takes the x-th contiguous eighth of the Morton curve, C >= 2 = the curve
  *                               is cut into chunks of C workgroups dealt round-robin to the XCDs (compact pieces
  *                               of space per L2, and all XCDs finish together)
