@@ -162,6 +162,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "fast_div") c->opt_fast_div = value != 0;
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "flat_project") c->opt_flat_project = value != 0;
+    else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)

@@ -79,7 +79,9 @@ struct alignas(64) ViewDesc {
     double width, height;   // bounds of the visibility test                        (dls.py:80)
     int seg_w, seg_h;
     int cam_w, cam_h;   // camera width / height as integers (visibility test of the certified path)
-    int pad_[4];
+    int coarse_row_bytes;   // bytes per strip of 16 coarse cells (0: this view has no coarse level)
+    unsigned coarse_delta;  // byte offset of the coarse level from the map's own start
+    int pad_[2];
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
 };
@@ -115,6 +117,7 @@ struct Ctx {
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
+    int opt_seg_coarse = 1;    // keep a 4x4-coarsened level of every tiled map (views staged after the call)
     int opt_flat_project = 1;  // branchless projection block (exact divisions, one predicate at the end)
 
     // vote
@@ -129,8 +132,9 @@ struct Ctx {
     DevBuf d_cull;               // double[25][cull_pitch]: five world-space culling planes per staged view
     int cull_pitch = 0;
     DevBuf d_cull_tally;         // u64: (wave, view) pairs skipped by the culling since the last reset
-    int opt_wave_cull = 0;       // skip (wave, view) pairs whose 64 Gaussians provably all miss the frame (measured: no gain)
+    int opt_wave_cull = 1;       // skip (wave, view) pairs whose 64 Gaussians provably all miss the frame
     bool views_dirty = true;  // host views newer than d_views
+    bool views_coarse = false;  // ... and a coarse level (set by sync_views)
     bool views_simple = false;  // every staged view: unit scale + tiled map (set by sync_views)
     DevBuf d_views;
     DevBuf segpool;

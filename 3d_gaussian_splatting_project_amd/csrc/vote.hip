@@ -57,6 +57,8 @@ struct ViewRegs {
     double R[9], t[3], fx, fy, half_w, half_h, width, height;
     long long seg_off;
     int seg_w, unit_scale, seg_row_bytes, cam_w, cam_h;
+    int coarse_row_bytes;
+    unsigned coarse_delta;
 };
 
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -70,7 +72,7 @@ __device__ __forceinline__ double chunk_f64(const v16i& v, int k) {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
-// The hot 176 bytes of a ViewDesc as four scalar loads (x16, x16, x8, x4), pinned as whole register tuples: the
+// The hot 184 bytes of a ViewDesc as four scalar loads (x16, x16, x8, x8), pinned as whole register tuples: the
 // fields below are sub-registers of those tuples, no scalar move is spent on them.  (Pinning the 24 fields one
 // by one cost 15 s_mov per view; the scalar unit is shared by the four SIMDs of a CU and every wave issues at
 // most one instruction per turn, so scalar bookkeeping was costing as much as the fp64 arithmetic.)
@@ -92,13 +94,14 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
                       offsetof(ViewDesc, seg_off) == 112 && offsetof(ViewDesc, seg_row_bytes) == 120 &&
                       offsetof(ViewDesc, unit_scale) == 124 && offsetof(ViewDesc, half_w) == 128 &&
                       offsetof(ViewDesc, width) == 144 && offsetof(ViewDesc, seg_w) == 160 &&
-                      offsetof(ViewDesc, cam_w) == 168 && sizeof(ViewDesc) % 64 == 0,
-                  "load_view reads the hot part of ViewDesc as 64 + 64 + 32 + 16 bytes");
+                      offsetof(ViewDesc, cam_w) == 168 && offsetof(ViewDesc, coarse_row_bytes) == 176 &&
+                      offsetof(ViewDesc, coarse_delta) == 180 && sizeof(ViewDesc) % 64 == 0,
+                  "load_view reads the hot part of ViewDesc as 64 + 64 + 32 + 32 bytes");
     const char* q = reinterpret_cast<const char*>(vp);
     v16i a = *reinterpret_cast<const v16i*>(q);
     v16i b = *reinterpret_cast<const v16i*>(q + 64);
     v8i c = *reinterpret_cast<const v8i*>(q + 128);
-    v4i d = *reinterpret_cast<const v4i*>(q + 160);
+    v8i d = *reinterpret_cast<const v8i*>(q + 160);
     asm volatile("" : "+s"(a), "+s"(b), "+s"(c), "+s"(d));
     ViewRegs r;
     unpack_core(r, a, b);
@@ -114,6 +117,8 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
     r.seg_w = d[0];
     r.cam_w = d[2];
     r.cam_h = d[3];
+    r.coarse_row_bytes = d[4];
+    r.coarse_delta = (unsigned)d[5];
     return r;
 }
 
@@ -140,7 +145,8 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
 //   same results; lanes the reference rejects early merely compute values nobody reads.
 // DIV == kDivFlatSimple: kDivFlat for a batch whose views ALL have unit scale and tiled maps (the host checks): the
 //   two wave-uniform tests per view disappear from the instruction stream.
-enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2, kDivFlatSimple = 3 };
+// DIV == kDivFlatCoarse: kDivFlatSimple for a batch whose maps all carry a coarse level (see gather_chunk).
+enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2, kDivFlatSimple = 3, kDivFlatCoarse = 4 };
 
 // Two IEEE-754 divisions by the same denominator, bit-identical to `ax / b` and `ay / b`.
 // hipcc expands an fp64 division into div_scale(den), rcp, two Newton steps, div_scale(num), mul, fma, div_fmas,
@@ -174,7 +180,7 @@ __device__ __forceinline__ void div2_shared(double ax, double ay, double b, doub
 template <int DIV>
 __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, double Z, int& xi, int& yi) {
     const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
-    if (DIV == kDivFlat || DIV == kDivFlatSimple) {
+    if (DIV == kDivFlat || DIV == kDivFlatSimple || DIV == kDivFlatCoarse) {
         // one wave-uniform early-out keeps what matters of the branchy form: a wave whose 64 Gaussians are all
         // behind the camera (Morton order makes that the common way to be culled) skips the view
         if (__builtin_amdgcn_ballot_w64(pc2 > 0.0) == 0) return false;
@@ -339,6 +345,26 @@ __global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ 
     if (bad) atomicOr(err, 1);
 }
 
+// coarse level of a strip-stored map: one thread = one 4x4 cell; 255 = "the 16 pixels differ" (or the cell sticks
+// out of the map), otherwise their common bin.  Same strip layout one level up (16 cells x 8 cell rows per line).
+__global__ __launch_bounds__(kBlock) void seg_coarse_kernel(const uint8_t* __restrict__ fine, uint8_t* __restrict__ coarse,
+                                                            int w, int h, int strip_bytes, int cstrip_bytes, int cw, int ch) {
+    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const int cy = (int)(q / cw), cx = (int)(q % cw);
+    if (cy >= ch) return;
+    const int x0 = cx * 4, y0 = cy * 4;
+    uint32_t value = 255;
+    if (x0 + 4 <= w && y0 + 4 <= h) {
+        const uint8_t* p = fine + (long long)(x0 >> 4) * strip_bytes + (x0 & 15) + ((long long)y0 << 4);
+        const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p);
+        const uint32_t same = (r0 & 0xffu) * 0x01010101u;
+        const bool uniform = r0 == same && *reinterpret_cast<const uint32_t*>(p + 16) == same &&
+                             *reinterpret_cast<const uint32_t*>(p + 32) == same && *reinterpret_cast<const uint32_t*>(p + 48) == same;
+        if (uniform) value = r0 & 0xffu;
+    }
+    coarse[(long long)(cx >> 4) * cstrip_bytes + (cx & 15) + ((long long)cy << 4)] = (uint8_t)value;
+}
+
 // -------------------------------------------------------------------------------------------------
 // fused vote, single GPU / single batch: labels straight out of the kernel
 // -------------------------------------------------------------------------------------------------
@@ -433,9 +459,44 @@ __device__ __forceinline__ unsigned cull_bits(const CullMasks& k, int done) {
 
 // One chunk of U views (vb-1, vb-2, ..): bin[u] = the vote of this lane's Gaussian in view vb-1-u, or -1.
 // FULL: all U views exist (no index test).  culled: bit u set = the whole wave provably misses view vb-1-u.
+typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
+
 template <int U, int DIV, bool FULL>
 __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views, const uint8_t* __restrict__ pool, int vb,
                                              double X, double Y, double Z, unsigned culled, int (&bin)[U]) {
+    if (DIV == kDivFlatCoarse) {
+        // Two-level lookup.  Every map carries a 4x4-coarsened copy whose cell holds the label shared by its 16
+        // pixels, or 255 where they differ.  The patch of pixels a wave gathers is ~30 px wide and costs ~16 L2
+        // requests per view in the full-resolution map (one per 128-B line = 16x8 pixels; the L2 request rate, not
+        // HBM, is what the kernel waits for) but ~3 in the coarse one (a line = 64x32 pixels).  Phase A gathers
+        // the coarse cells of all U views; phase B re-reads the exact pixel only for lanes that hit a mixed cell
+        // (segment boundaries).  A uniform cell IS the pixel's label, so results do not change.
+        unsigned fine[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb - 1 - u;
+            bin[u] = -1;
+            fine[u] = 0;
+            if (((culled >> u) & 1u) || !(FULL || v >= 0)) continue;  // wave-uniform
+            const ViewRegs vd = load_view(views + v);
+            int xi, yi;
+            if (project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
+                fine[u] = __umul24((unsigned)xi >> 4, (unsigned)vd.seg_row_bytes) + ((unsigned)xi & 15u) + ((unsigned)yi << 4);
+                const unsigned cx = (unsigned)xi >> 2, cy = (unsigned)yi >> 2;
+                const unsigned coff = __umul24(cx >> 4, (unsigned)vd.coarse_row_bytes) + (cx & 15u) + (cy << 4);
+                bin[u] = ((global_u8_ptr)((unsigned long long)vd.seg_off + vd.coarse_delta))[coff];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool mixed = bin[u] == 255;
+            if (__builtin_amdgcn_ballot_w64(mixed) != 0) {  // wave-uniform; rare away from segment boundaries
+                const global_u8_ptr base = (global_u8_ptr)(unsigned long long)views[vb - 1 - u].seg_off;
+                if (mixed) bin[u] = base[fine[u]];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const int v = vb - 1 - u;  // `v >= 0` is wave-uniform
@@ -880,7 +941,8 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
 // call after sync_views(): views_simple describes the staged batch
 static inline int div_mode(const Ctx* c) {
     if (!c->opt_flat_project) return c->opt_fast_div ? kDivCertified : kDivExact;
-    return c->views_simple ? kDivFlatSimple : kDivFlat;
+    if (!c->views_simple) return kDivFlat;
+    return c->views_coarse && c->opt_seg_coarse ? kDivFlatCoarse : kDivFlatSimple;
 }
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
@@ -993,7 +1055,13 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     const size_t off = (c->seg_used + 255) / 256 * 256;  // 256-B aligned maps
     // "tiled" maps are stored as strips of 16 columns; tiles_w = bytes per strip (rows padded to a multiple of 8)
     const int tiles_w = c->opt_seg_tiled ? (seg_h + 7) / 8 * 128 : 0;
-    const size_t map_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_w + 15) / 16) : (size_t)npix + 4;
+    const size_t fine_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_w + 15) / 16) : (size_t)npix + 4;
+    // coarse level (4x4 pixels per cell, same strip layout); bin 255 must be free to mean "mixed"
+    const bool coarse = tiles_w && c->opt_seg_coarse && c->bins <= 255;
+    const int cw = (seg_w + 3) / 4, ch = (seg_h + 3) / 4;
+    const int ctiles = coarse ? (ch + 7) / 8 * 128 : 0;
+    const size_t coarse_off = (fine_bytes + 255) / 256 * 256;
+    const size_t map_bytes = coarse ? coarse_off + (size_t)ctiles * (size_t)((cw + 15) / 16) : fine_bytes;
     if (map_bytes > 0xffffffffull)
         return fail(c, GSX_E_RANGE, "vote_view: segmentation map %dx%d exceeds 4 GiB", seg_w, seg_h);
     int rc = pool_reserve(c, off + map_bytes);
@@ -1019,6 +1087,11 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
             hipLaunchKernelGGL(seg_pack_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const uint8_t*)src, dst,
                                seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
     }
+    if (coarse) {
+        ProfScope ps(c, "seg_coarse");
+        hipLaunchKernelGGL(seg_coarse_kernel, dim3(grid_for((long long)cw * ch)), dim3(kBlock), 0, c->stream, dst,
+                           dst + coarse_off, seg_w, seg_h, tiles_w, ctiles, cw, ch);
+    }
     GSX_HIP(c, hipGetLastError());
     int bad = 0;
     GSX_HIP(c, hipMemcpyAsync(&bad, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1031,6 +1104,8 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device
     fill_view_desc(vd, cam, seg_w, seg_h, img_w, img_h);
     vd.seg_off = (long long)off;
     vd.seg_row_bytes = tiles_w;
+    vd.coarse_row_bytes = ctiles;
+    vd.coarse_delta = (unsigned)coarse_off;
     c->views.push_back(vd);
     c->views_dirty = true;
     c->seg_used = off + map_bytes;
@@ -1109,6 +1184,7 @@ static int sync_views(Ctx* c) {
     const size_t bytes = sizeof(ViewDesc) * (c->views.empty() ? 1 : c->views.size());
     GSX_HIP(c, c->d_views.ensure(bytes));
     c->views_simple = !c->views.empty();
+    c->views_coarse = c->views_simple;
     if (!c->views.empty()) {
         // device copy: seg_off becomes the absolute address of the map (one scalar add less per view and wave)
         std::vector<ViewDesc> dev(c->views);
@@ -1116,6 +1192,7 @@ static int sync_views(Ctx* c) {
         for (ViewDesc& v : dev) {
             v.seg_off += base;
             c->views_simple = c->views_simple && v.unit_scale && v.seg_row_bytes;
+            c->views_coarse = c->views_coarse && v.coarse_row_bytes;
         }
         GSX_HIP(c, hipMemcpyAsync(c->d_views.p, dev.data(), sizeof(ViewDesc) * dev.size(), hipMemcpyHostToDevice, c->stream));
         // culling planes, plane-component-major so that lane l reads view l with unit stride
@@ -1232,7 +1309,8 @@ int vote_flush(Ctx* c) {
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
             const int dm = div_mode(c);
-            auto k = dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatSimple>
+            auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatCoarse>
+                     : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatSimple>
                      : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlat>
                      : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified>
                                            : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
@@ -1241,7 +1319,8 @@ int vote_flush(Ctx* c) {
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
         } else {
             const int dm = div_mode(c);
-            auto k = dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
+            auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
+                     : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
                      : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat>
                      : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified>
                                            : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
@@ -1335,8 +1414,9 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
     {{vote_fused_labels_kernel<U_, kDivExact, false>, vote_fused_labels_kernel<U_, kDivExact, true>},         \
      {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
      {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>},           \
-     {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}}
-            static const K table[3][4][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
+     {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}, \
+     {vote_fused_labels_kernel<U_, kDivFlatCoarse, false>, vote_fused_labels_kernel<U_, kDivFlatCoarse, true>}}
+            static const K table[3][5][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
 #undef GSX_ROW
             K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
             if ((rc = set_lds(c, k, lds))) return rc;
@@ -1386,7 +1466,8 @@ int vote_flush_counts(Ctx* c) {
         FusedParams p = fused_params(c, 1);
         const size_t lds = (size_t)kBlock * p.stride_dw * 4;
         const int dm = div_mode(c);
-        auto k = dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
+        auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+                 : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
                  : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
                  : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
                                        : vote_fused_counts_kernel<kUnroll, kDivExact>;

@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--classes", type=int, default=150)
+    ap.add_argument("--seg-cell", type=int, default=4,
+                    help="synthetic maps: Voronoi regions evaluated on a grid of this many pixels (4 = the round's workload; "
+                         "1 = pixel-accurate boundaries, the hard case for the coarse map level)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="cap on CPU-baseline OpenMP threads (box CPU share)")
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="Gaussians in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--order", default="input", choices=["input", "morton_host"],
@@ -150,7 +153,7 @@ def main():
     keep_host = rank == 0 and world == 1 and args.cpu_sample > 0
     ingest_s = 0.0
     for v in range(V):
-        seg = scene.make_segmap(H, W, args.classes, 3000 + first + v)
+        seg = scene.make_segmap(H, W, args.classes, 3000 + first + v, cell=args.seg_cell)
         t1 = time.perf_counter()
         ctx.vote_view(cams_all[first + v], seg)          # host int32 map -> PCIe -> u8 tiles in HBM (synchronous)
         ingest_s += time.perf_counter() - t1
@@ -275,7 +278,8 @@ def main():
             "config": {"workload": f"{n} Gaussians x {V} views/GPU @{W}x{H}, {args.classes} classes + (-1), "
                                    f"BASELINE configs[{2 if world == 1 else 3}]",
                        "gaussians": n, "views_per_gpu": V, "views_total": total_views, "width": W, "height": H,
-                       "classes": args.classes, "parallelism": f"views sharded x{world}",
+                       "classes": args.classes, "seg_maps": f"Voronoi, 400 sites, evaluated on a {args.seg_cell}-px grid",
+                       "parallelism": f"views sharded x{world}",
                        "exchange": None if world == 1 else ("all_to_all(counts) + sparse tie pass + all_gather(labels)" if use_sparse else
                                                             "all_to_all + slab arg-max + all_gather(labels)" if use_a2a else
                                                             "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"),

@@ -77,7 +77,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
                  {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0},
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
                  {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
@@ -207,6 +207,37 @@ def test_planes_content_vs_recount(ctx):
     cnt, fv = ctx.debug_planes(151)
     sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 3, 40)
     assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
+
+
+def test_coarse_level_with_pixel_accurate_boundaries(gsx):
+    """Maps whose segment boundaries run through the 4x4 cells of the coarse level (Voronoi evaluated per pixel), with
+    sizes that are not multiples of 4 or 16: uniform cells answer from the coarse level, mixed and edge cells from the
+    full-resolution map; the labels equal the oracle's and the vote planes equal those of the one-level path."""
+    n, V = 120_000, 10
+    pos = scene.make_positions(n, 77)
+    for (W, H) in ((203, 157), (640, 362), (97, 64)):
+        cams = scene.make_cameras(V, W, H, convention="w2c")
+        segs = [scene.make_segmap(H, W, 150, 4000 + v, n_sites=60, cell=1) for v in range(V)]
+        segs[1] = np.random.default_rng(1).integers(-1, 150, size=(H, W)).astype(np.int32)   # every cell mixed
+        segs[2] = np.full((H, W), 17, np.int32)                                                # every cell uniform
+        sizes = [(W, H)] * V
+        want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+        planes = {}
+        for coarse in (1, 0):
+            with gsx.Context(0) as c:
+                c.set_option("seg_coarse", coarse)
+                assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want), (W, H, coarse)
+                c.vote_rewind()
+                c.vote_flush()
+                planes[coarse] = c.debug_planes(151)
+        assert np.array_equal(planes[1][0], planes[0][0]) and np.array_equal(planes[1][1], planes[0][1])
+    # 255 classes: bin 255 is a real label, the coarse level must switch itself off
+    cams = scene.make_cameras(3, 64, 48, convention="w2c")
+    segs = [np.random.default_rng(v).integers(-1, 255, size=(48, 64)).astype(np.int32) // 1 for v in range(3)]
+    segs[0][:] = 254
+    with gsx.Context(0) as c:
+        got = run_gpu(c, pos[:5000], cams, segs, [(64, 48)] * 3, n_classes=255).vote_finalize()
+    assert np.array_equal(got, oracle.assign_labels(pos[:5000], cams, segs, [(64, 48)] * 3, threads=0)) and (got == 254).any()
 
 
 def test_wave_culling_changes_no_vote(gsx):
@@ -502,6 +533,7 @@ def test_randomised_small_configurations(gsx):
             c.set_option("fast_div", int(rng.integers(0, 2)))
             c.set_option("flat_project", int(rng.integers(0, 2)))
             c.set_option("wave_cull", int(rng.integers(0, 2)))
+            c.set_option("seg_coarse", int(rng.integers(0, 2)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
             for v in range(V):
