@@ -471,17 +471,17 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
         // HBM, is what the kernel waits for) but ~3 in the coarse one (a line = 64x32 pixels).  Phase A gathers
         // the coarse cells of all U views; phase B re-reads the exact pixel only for lanes that hit a mixed cell
         // (segment boundaries).  A uniform cell IS the pixel's label, so results do not change.
-        unsigned fine[U];
+        unsigned pixel[U];  // xi | yi << 16 (both < 65536): the full-resolution offset is only worked out if needed
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int v = vb - 1 - u;
             bin[u] = -1;
-            fine[u] = 0;
+            pixel[u] = 0;
             if (((culled >> u) & 1u) || !(FULL || v >= 0)) continue;  // wave-uniform
             const ViewRegs vd = load_view(views + v);
             int xi, yi;
             if (project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
-                fine[u] = __umul24((unsigned)xi >> 4, (unsigned)vd.seg_row_bytes) + ((unsigned)xi & 15u) + ((unsigned)yi << 4);
+                pixel[u] = (unsigned)xi | ((unsigned)yi << 16);
                 const unsigned cx = (unsigned)xi >> 2, cy = (unsigned)yi >> 2;
                 const unsigned coff = __umul24(cx >> 4, (unsigned)vd.coarse_row_bytes) + (cx & 15u) + (cy << 4);
                 bin[u] = ((global_u8_ptr)((unsigned long long)vd.seg_off + vd.coarse_delta))[coff];
@@ -491,8 +491,10 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
         for (int u = 0; u < U; ++u) {
             const bool mixed = bin[u] == 255;
             if (__builtin_amdgcn_ballot_w64(mixed) != 0) {  // wave-uniform; rare away from segment boundaries
-                const global_u8_ptr base = (global_u8_ptr)(unsigned long long)views[vb - 1 - u].seg_off;
-                if (mixed) bin[u] = base[fine[u]];
+                const ViewDesc* __restrict__ vp = views + (vb - 1 - u);
+                const global_u8_ptr base = (global_u8_ptr)(unsigned long long)vp->seg_off;
+                const unsigned xi = pixel[u] & 0xffffu, yi = pixel[u] >> 16;
+                if (mixed) bin[u] = base[__umul24(xi >> 4, (unsigned)vp->seg_row_bytes) + (xi & 15u) + (yi << 4)];
             }
         }
         return;
