@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd $ROOT
 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -3 $OUT/pytest.log
-for o in "" "--opt xcd_swizzle=4" "--opt xcd_swizzle=8" "--opt xcd_swizzle=32" "--opt xcd_swizzle=1" "--opt wave_cull=1" "--opt flat_project=0" "--opt xcd_swizzle=0" "--opt seg_tiled=0" "--opt spatial_sort=0" ""; do
+for o in "" "--seg-cell 1" "--opt wave_cull=0" "--opt seg_coarse=0" "--opt seg_coarse=0 --opt wave_cull=0" "--opt xcd_swizzle=1" "--opt flat_project=0" "--opt xcd_swizzle=0" "--opt seg_tiled=0" "--opt spatial_sort=0" ""; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-sample 0 --render-views 0 $o 2>/dev/null \
     | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$o', d['ms_per_step'], d['roofline']['kernel_ms'], d['value'])" | tee -a $OUT/sweep.log
 done
