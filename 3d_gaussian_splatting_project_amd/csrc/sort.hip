@@ -276,30 +276,44 @@ __global__ void bbox_final_kernel(const float* __restrict__ partial, int nparts,
     }
 }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {
-    v = (v | (v << 16)) & 0x030000FFu;
-    v = (v | (v << 8)) & 0x0300F00Fu;
-    v = (v | (v << 4)) & 0x030C30C3u;
-    return (v | (v << 2)) & 0x09249249u;
+// 21 bits -> every third bit of a 63-bit word
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x1f00000000ffffull;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    return (v | (v << 2)) & 0x1249249249249249ull;
 }
 
+// 63-bit Morton code, 21 bits per axis: a scene with far outliers (floaters at 1000x the scene radius are common in
+// trained captures) still has ~2000 cells across its dense part, where 10 bits per axis would leave two.
 __global__ __launch_bounds__(kSortBlock) void morton_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                              const float* __restrict__ z, long long n,
                                                              const float* __restrict__ box,
-                                                             uint32_t* __restrict__ code, uint32_t* __restrict__ idx) {
+                                                             uint32_t* __restrict__ code_lo, uint32_t* __restrict__ code_hi,
+                                                             uint32_t* __restrict__ idx) {
     const long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x;
     if (i >= n) return;
     const float v[3] = {x[i], y[i], z[i]};
-    uint32_t q[3];
+    unsigned long long q[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float ext = box[3 + a] - box[a];
-        float t = ext > 0.0f ? (v[a] - box[a]) / ext * 1023.0f : 0.0f;
-        t = (t - t == 0.0f) ? fminf(fmaxf(t, 0.0f), 1023.0f) : 0.0f;  // non-finite positions sort first
-        q[a] = (uint32_t)t;
+        const double ext = (double)box[3 + a] - (double)box[a];
+        double t = ext > 0.0 ? ((double)v[a] - (double)box[a]) / ext * 2097151.0 : 0.0;
+        t = (t - t == 0.0) ? fmin(fmax(t, 0.0), 2097151.0) : 0.0;  // non-finite positions sort first
+        q[a] = (unsigned long long)t;
     }
-    code[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+    const unsigned long long code = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+    code_lo[i] = (uint32_t)code;
+    code_hi[i] = (uint32_t)(code >> 32);
     idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(kSortBlock) void gather1_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ perm,
+                                                              long long n, uint32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kSortBlock + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
 }
 
 __global__ __launch_bounds__(kSortBlock) void gather3_kernel(const float* __restrict__ x, const float* __restrict__ y,
@@ -315,15 +329,16 @@ __global__ __launch_bounds__(kSortBlock) void gather3_kernel(const float* __rest
     oz[i] = z[s];
 }
 
-// Reorders c->x/y/z along a 30-bit Morton curve; c->perm[i] = original index of sorted slot i.
+// Reorders c->x/y/z along a 63-bit Morton curve; c->perm[i] = original index of sorted slot i.
 int spatial_sort_positions(Ctx* c) {
     const long long n = c->n;
     c->sorted = false;
     if (n < 2) return GSX_OK;
     const size_t nb = sizeof(uint32_t) * (size_t)n;
-    DevBuf code0, code1, idx1, box, tx, ty, tz;
+    DevBuf code0, code1, codeh, idx1, box, tx, ty, tz;
     GSX_HIP(c, code0.ensure(nb));
     GSX_HIP(c, code1.ensure(nb));
+    GSX_HIP(c, codeh.ensure(nb));
     GSX_HIP(c, idx1.ensure(nb));
     GSX_HIP(c, c->perm.ensure(nb));
     const int parts = 512;
@@ -335,15 +350,26 @@ int spatial_sort_positions(Ctx* c) {
                        c->z.as<float>(), n, partial);
     hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, c->stream, partial, parts, bb);
     hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(kSortBlock), 0, c->stream, c->x.as<float>(), c->y.as<float>(),
-                       c->z.as<float>(), n, bb, code0.as<uint32_t>(), c->perm.as<uint32_t>());
+                       c->z.as<float>(), n, bb, code0.as<uint32_t>(), codeh.as<uint32_t>(), c->perm.as<uint32_t>());
     GSX_HIP(c, hipGetLastError());
+    // stable LSD sort of the 63-bit code: by its low word, then by its high word (gathered into the new order)
+    uint32_t* idx[2] = {c->perm.as<uint32_t>(), idx1.as<uint32_t>()};
     int where = 0;
-    int rc = radix_sort_pairs(c, code0.as<uint32_t>(), c->perm.as<uint32_t>(), code1.as<uint32_t>(), idx1.as<uint32_t>(), n, 30,
-                              &where);
+    int rc = radix_sort_pairs(c, code0.as<uint32_t>(), idx[0], code1.as<uint32_t>(), idx[1], n, 32, &where);
     if (!rc) {
-        if (where == 1) {
-            hipError_t e = hipMemcpyAsync(c->perm.p, idx1.p, nb, hipMemcpyDeviceToDevice, c->stream);
-            if (e != hipSuccess) rc = fail(c, GSX_E_HIP, "spatial sort: %s", hipGetErrorString(e));
+        uint32_t* sorted_idx = idx[where];
+        uint32_t* other_idx = idx[where ^ 1];
+        hipLaunchKernelGGL(gather1_kernel, dim3(grid), dim3(kSortBlock), 0, c->stream, codeh.as<uint32_t>(), sorted_idx, n,
+                           code0.as<uint32_t>());
+        GSX_HIP(c, hipGetLastError());
+        int where2 = 0;
+        rc = radix_sort_pairs(c, code0.as<uint32_t>(), sorted_idx, code1.as<uint32_t>(), other_idx, n, 31, &where2);
+        if (!rc) {
+            uint32_t* final_idx = where2 ? other_idx : sorted_idx;
+            if (final_idx != c->perm.as<uint32_t>()) {
+                hipError_t e = hipMemcpyAsync(c->perm.p, final_idx, nb, hipMemcpyDeviceToDevice, c->stream);
+                if (e != hipSuccess) rc = fail(c, GSX_E_HIP, "spatial sort: %s", hipGetErrorString(e));
+            }
         }
     }
     if (!rc) {
@@ -365,7 +391,7 @@ int spatial_sort_positions(Ctx* c) {
         }
     }
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&code0, &code1, &idx1, &box, &tx, &ty, &tz}) b->release();
+    for (DevBuf* b : {&code0, &code1, &codeh, &idx1, &box, &tx, &ty, &tz}) b->release();
     return rc;
 }
 

@@ -209,6 +209,25 @@ def test_planes_content_vs_recount(ctx):
     assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
 
 
+def test_far_outliers_do_not_flatten_the_spatial_order(gsx):
+    """A few floaters at 10^4 scene radii (common in trained captures) must not degrade the Morton order of the dense
+    part: the share of (wave, view) pairs the culling can skip - a direct measure of how compact the waves are -
+    stays what it is without them, and the labels stay exact."""
+    n, V = 300_000, 16
+    pos, cams, segs = scene.make_scene(n, V, 480, 270, config_id=21, convention="w2c")
+    sizes = [(480, 270)] * V
+    far = pos.copy()
+    far[::50_000] = np.float32(1e5) * np.sign(far[::50_000] + np.float32(1e-3))     # six floaters in six octants
+    share = {}
+    for name, p in (("plain", pos), ("floaters", far)):
+        with gsx.Context(0) as c:
+            labels = run_gpu(c, p, cams, segs, sizes).vote_finalize()
+            share[name] = c.vote_culled() / (((n + 63) // 64) * V)
+            sample = np.arange(0, n, 37)
+            assert np.array_equal(labels[sample], oracle.assign_labels(np.ascontiguousarray(p[sample]), cams, segs, sizes, threads=0))
+    assert share["plain"] > 0.15 and share["floaters"] > 0.9 * share["plain"], share
+
+
 def test_coarse_level_with_pixel_accurate_boundaries(gsx):
     """Maps whose segment boundaries run through the 4x4 cells of the coarse level (Voronoi evaluated per pixel), with
     sizes that are not multiples of 4 or 16: uniform cells answer from the coarse level, mixed and edge cells from the
