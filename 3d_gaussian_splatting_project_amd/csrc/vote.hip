@@ -475,8 +475,7 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int v = vb - 1 - u;
-            bin[u] = -1;
-            pixel[u] = 0;
+            bin[u] = -1;  // (pixel[u] is only read where bin[u] == 255, i.e. where it was set below)
             if (((culled >> u) & 1u) || !(FULL || v >= 0)) continue;  // wave-uniform
             const ViewRegs vd = load_view(views + v);
             int xi, yi;

@@ -99,7 +99,12 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "tile_lpt"     (default 0)  rasterizer: blend the tiles with the longest splat lists first (measured:
  *                               blend -3 %, paid back by the extra ordering launches)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as strips of 16 pixel columns (16x8 pixels per 128-B line;
- *                               applies to the views staged after the call) */
+ *                               applies to the views staged after the call)
+ *   "seg_coarse"   (default 1)  keep a second, 4x4-coarsened level of every strip-stored map (a cell holds the label
+ *                               its 16 pixels share, or 255) and look a vote up there first; only lanes that hit a
+ *                               mixed cell read the full-resolution map.  Same labels; a wave then touches ~3 cache
+ *                               lines per view instead of ~16 (HBM traffic per launch 5.2 GB -> 0.5 GB).  Needs
+ *                               n_classes <= 254, unit scale and "seg_tiled"; otherwise the one-level path runs */
 int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value);
 
 /* ---------------------------------------------------------------------------------------------
