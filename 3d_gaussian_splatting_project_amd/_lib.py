@@ -101,6 +101,8 @@ _SIGS = {
     "gsx_ply_read_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "gsx_ply_set_f32": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p]),
     "gsx_ply_write": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]),
+    "gsx_kmeans": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
+                             C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsx_vote_culled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
     "gsx_debug_cull_planes": (C.c_int, [C.POINTER(Camera), C.c_void_p]),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),

@@ -402,6 +402,14 @@ int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uin
     return gsx::render_debug(c, buffer_out, order_out, texdata_out, bucket_out);
 }
 
+int gsx_kmeans(gsx_ctx* ctx, int64_t n, const float* points, const float* colors, int32_t k, const int64_t* init_index,
+               int32_t max_iter, double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out,
+               int32_t* converged_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::kmeans(c, n, points, colors, k, init_index, max_iter, tol, labels_out, centroids_out, iterations_out,
+                       converged_out);
+}
+
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset) {
     CTX_OR_FAIL(ctx);
     if (!wave_views) return gsx::fail(c, GSX_E_INVALID, "vote_culled: NULL argument");

@@ -208,6 +208,8 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
                      int* result_in);
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
+int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, const int64_t* init_index, int max_iter,
+           double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out, int32_t* converged_out);
 void debug_cull_planes(const gsx_camera* cam, double* out);
 // render.hip
 int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const float* rot, const float* opacity,

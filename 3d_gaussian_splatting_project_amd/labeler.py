@@ -191,6 +191,23 @@ class Context:
               self.h)
         return out
 
+    def kmeans(self, points, colors, k, init_index, max_iter=100, tol=1e-4):
+        """k_means_with_color (3D_clustering/k_means.py:107-151) with injected initial rows.
+        Returns (centroids float32 (k, 6), labels int32 (n,), iterations, converged)."""
+        pts = np.ascontiguousarray(points, np.float32).reshape(-1, 3)
+        col = np.ascontiguousarray(colors, np.float32).reshape(-1, 3)
+        if len(pts) != len(col):
+            raise ValueError("points and colors differ in length")
+        init = np.ascontiguousarray(init_index, np.int64)
+        if init.shape != (int(k),):
+            raise ValueError("init_index must hold k row indices")
+        labels = np.empty(len(pts), np.int32)
+        cent = np.empty((int(k), 6), np.float32)
+        iters, conv = C.c_int32(0), C.c_int32(0)
+        check(self._lib.gsx_kmeans(self.h, len(pts), pts.ctypes.data, col.ctypes.data, int(k), init.ctypes.data, int(max_iter),
+                                   float(tol), labels.ctypes.data, cent.ctypes.data, C.byref(iters), C.byref(conv)), self.h)
+        return cent, labels, int(iters.value), bool(conv.value)
+
     def vote_culled(self, reset=False):
         """(wave, view) pairs skipped by the wave culling so far (gsx_vote_culled)."""
         out = C.c_int64(0)

@@ -298,6 +298,21 @@ int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);
 int gsx_debug_cull_planes(const gsx_camera* cam, double* out);
 
 /* ---------------------------------------------------------------------------------------------
+ * k-means labeler: 3D_clustering/k_means.py:107-151 k_means_with_color (the reference's other producer of the
+ * `label` field).  points / colors: n x 3 float32 each, row-major, on the host (x y z and
+ * f_dc_0..2, k_means.py:17-28).  init_index[k]: the rows used as initial centroids - the reference draws them
+ * with an unseeded np.random.choice (k_means.py:111), so the caller supplies them.  Runs at most max_iter
+ * rounds of assign (nearest centroid by float64 squared distance in scipy's summation order, :116-122) and
+ * update (float32 mean with numpy's in-order accumulation, :125-128), stops early when the centroids moved by
+ * less than tol (:132-136), and labels every row by the centroids in hand (:142-147).
+ * labels_out int32[n] (required); centroids_out float32[k*6], iterations_out, converged_out may be NULL.
+ * 1 <= k <= min(n, 2048).
+ * ------------------------------------------------------------------------------------------- */
+int gsx_kmeans(gsx_ctx* ctx, int64_t n, const float* points, const float* colors, int32_t k, const int64_t* init_index,
+               int32_t max_iter, double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out,
+               int32_t* converged_out);
+
+/* ---------------------------------------------------------------------------------------------
  * profiling hooks (HIP events on the ctx stream around each kernel launch)
  * ------------------------------------------------------------------------------------------- */
 int gsx_profile_enable(gsx_ctx* ctx, int on);
