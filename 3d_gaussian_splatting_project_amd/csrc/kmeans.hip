@@ -8,8 +8,8 @@
 //   update   (k_means.py:125-128)  numpy's float32 mean over axis 0 adds the member rows IN INDEX ORDER into a float32
 //            accumulator.  Floating-point addition does not reassociate, so the sum is made the same way: a stable
 //            radix sort of the row indices by label puts every cluster's members in index order, and one wave per
-//            cluster adds them one after the other (all 64 lanes stage 64 rows at a time through LDS, six lanes - one
-//            per dimension - do the adds).  The division by float32(count) and the convergence test (:132-136) run on
+//            workgroup per cluster adds them one after the other (fifteen waves stage the rows through an LDS ring,
+//            six lanes - one per dimension - do the adds).  The division by float32(count) and the convergence test (:132-136) run on
 //            the host.
 //
 // Data layout in HBM: rows float[n][6] (24 B, AoS as in the PLY), labels u32[n], order u32[n] (row indices grouped by
@@ -63,40 +63,55 @@ __global__ __launch_bounds__(kKmBlock) void kmeans_assign_kernel(const float* __
         if (lc[t]) atomicAdd(&counts[t], lc[t]);
 }
 
-// one wave per cluster: sums[c][d] = ((row[o0][d] + row[o1][d]) + row[o2][d]) + ... in float32, members in index order
-__global__ __launch_bounds__(64) void kmeans_sum_kernel(const float* __restrict__ rows, const uint32_t* __restrict__ order,
-                                                         const uint32_t* __restrict__ offsets /*[k+1]*/,
-                                                         float* __restrict__ sums) {
-    __shared__ float stage[2][64][6];
-    const int c = blockIdx.x, lane = threadIdx.x;
+// One workgroup per cluster: sums[c][d] = ((row[o0][d] + row[o1][d]) + row[o2][d]) + ... in float32, members in
+// index order.  The chain of additions is serial by definition, so the kernel only makes sure it never waits for
+// memory: waves 1..15 fetch the next 960 member rows into one half of an LDS ring while lanes 0..5 of wave 0 (one per
+// dimension) add the previous 960 from the other half.
+static constexpr int kSumThreads = 1024;
+static constexpr int kSumRows = kSumThreads - 64;
+__global__ __launch_bounds__(kSumThreads) void kmeans_sum_kernel(const float* __restrict__ rows,
+                                                                 const uint32_t* __restrict__ order,
+                                                                 const uint32_t* __restrict__ offsets /*[k+1]*/,
+                                                                 float* __restrict__ sums) {
+    __shared__ float stage[2][kSumRows][6];
+    const int c = blockIdx.x, tid = threadIdx.x;
     const uint32_t beg = offsets[c], end = offsets[c + 1];
     float acc = 0.0f;
     bool first = true;  // numpy's reduction starts FROM the first row, not from +0.0 (the sign of a zero sum)
-    auto load = [&](uint32_t t0, int buf) {
-        const uint32_t t = t0 + lane;
-        if (t < end) {
+    auto load = [&](uint32_t t0, int buf) {  // loader waves only
+        const uint32_t t = t0 + (uint32_t)(tid - 64);
+        if (tid >= 64 && t < end) {
             const float2* r = reinterpret_cast<const float2*>(rows + (size_t)order[t] * 6);
             const float2 a = r[0], b = r[1], d = r[2];
-            float* s = stage[buf][lane];
+            float* s = stage[buf][tid - 64];
             s[0] = a.x, s[1] = a.y, s[2] = b.x, s[3] = b.y, s[4] = d.x, s[5] = d.y;
         }
     };
     int buf = 0;
-    if (beg < end) load(beg, 0);
-    for (uint32_t t0 = beg; t0 < end; t0 += 64) {
-        __syncthreads();                              // stage[buf] is complete
-        if (t0 + 64 < end) load(t0 + 64, buf ^ 1);    // the next batch is on its way while this one is added
-        const int m = (int)min(64u, end - t0);
-        if (lane < 6) {
-            for (int j = 0; j < m; ++j) {
-                const float v = stage[buf][j][lane];
-                acc = first ? v : acc + v;
+    load(beg, 0);
+    for (uint32_t t0 = beg; t0 < end; t0 += kSumRows) {  // block-uniform trip count
+        __syncthreads();                                  // stage[buf] is complete, stage[buf ^ 1] is free
+        if (t0 + kSumRows < end) load(t0 + kSumRows, buf ^ 1);
+        if (tid < 6) {
+            const int m = (int)min((uint32_t)kSumRows, end - t0);
+            int j = 0;
+            if (first && m > 0) {
+                acc = stage[buf][0][tid];
                 first = false;
+                j = 1;
             }
+            for (; j + 16 <= m; j += 16) {  // 16 LDS reads in flight, then the 16 additions in order
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = stage[buf][j + u][tid];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc = acc + v[u];
+            }
+            for (; j < m; ++j) acc = acc + stage[buf][j][tid];
         }
         buf ^= 1;
     }
-    if (lane < 6) sums[c * 6 + lane] = acc;
+    if (tid < 6) sums[c * 6 + tid] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -169,7 +184,7 @@ int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, c
         GSX_HIP(c, hipMemcpyAsync(offsets.p, ho.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, c->stream));
         {
             ProfScope ps(c, "kmeans_sum");
-            hipLaunchKernelGGL(kmeans_sum_kernel, dim3(k), dim3(64), 0, c->stream, rows.as<float>(), order, offsets.as<uint32_t>(),
+            hipLaunchKernelGGL(kmeans_sum_kernel, dim3(k), dim3(kSumThreads), 0, c->stream, rows.as<float>(), order, offsets.as<uint32_t>(),
                                sums.as<float>());
             GSX_HIP(c, hipGetLastError());
         }
