@@ -637,8 +637,8 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
 // TIED (label -2 for now) and the set of max-count bins goes out as a bit mask, cand[word][sn], 8 words.
 static constexpr int kCandWords = 8;  // bins <= 256
 // One thread owns 4 consecutive Gaussians: every plane row is read as coalesced dwords (256 B per wave
-// instruction instead of 64 single bytes).  Two passes over the slab (maximum, then masks); parking the
-// totals in LDS instead was measured 2x slower (77 KB per wave leaves 2 waves per CU).
+// instruction instead of 64 single bytes).  (Two passes - maximum, then masks - read the slab twice: 0.37 ms;
+// parking the totals in LDS instead was 2x slower still, 77 KB per wave leaves 2 waves per CU.)
 __device__ __forceinline__ void slab_totals4(const uint8_t* __restrict__ rcnt, int S, int bins, long long sn, long long i4, int b,
                                              unsigned t[4]) {
     t[0] = t[1] = t[2] = t[3] = 0;
@@ -654,33 +654,45 @@ __global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t*
                                                                   uint32_t* __restrict__ cand) {
     const long long i4 = ((long long)blockIdx.x * kBlock + threadIdx.x) * 4;
     if (i4 >= sn) return;
+    // ONE pass over the planes: the mask of max-count bins is built against the running maximum; a word of 32 bins
+    // remembers the maximum its bits refer to, and only the words whose maximum is the final one survive.
     unsigned M[4] = {0, 0, 0, 0};
-#pragma unroll 4
-    for (int b = 0; b < bins; ++b) {
-        unsigned t[4];
-        slab_totals4(rcnt, S, bins, sn, i4, b, t);
+    uint32_t word[kCandWords][4];
+    unsigned wmax[kCandWords][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) M[k] = max(M[k], t[k]);
-    }
-    int n_max[4] = {0, 0, 0, 0}, first_bin[4] = {-1, -1, -1, -1};
     for (int w = 0; w < kCandWords; ++w) {
-        uint32_t word[4] = {0, 0, 0, 0};
-#pragma unroll 4
-        for (int bb = 0; bb < 32; ++bb) {
-            const int b = w * 32 + bb;
-            if (b >= bins) break;
-            unsigned t[4];
-            slab_totals4(rcnt, S, bins, sn, i4, b, t);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (M[k] > 0 && t[k] == M[k]) {
-                    word[k] |= 1u << bb;
-                    if (n_max[k] == 0) first_bin[k] = b;
-                    ++n_max[k];
+        for (int k = 0; k < 4; ++k) word[w][k] = 0, wmax[w][k] = 0;
+        if (w * 32 < bins) {  // wave-uniform
+            const int nb = min(32, bins - w * 32);
+#pragma unroll 4
+            for (int bb = 0; bb < nb; ++bb) {
+                unsigned t[4];
+                slab_totals4(rcnt, S, bins, sn, i4, w * 32 + bb, t);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (t[k] > M[k]) {  // a new maximum: the bits gathered so far in this word are void
+                        M[k] = t[k];
+                        word[w][k] = 0;
+                    }
+                    if (t[k] == M[k]) word[w][k] |= 1u << bb;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wmax[w][k] = M[k];
         }
-        *reinterpret_cast<uint4*>(cand + (long long)w * sn + i4) = make_uint4(word[0], word[1], word[2], word[3]);
+    }
+    int n_max[4] = {0, 0, 0, 0}, first_bin[4] = {-1, -1, -1, -1};
+#pragma unroll
+    for (int w = 0; w < kCandWords; ++w) {
+        uint32_t out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            out[k] = (M[k] > 0 && wmax[w][k] == M[k]) ? word[w][k] : 0u;
+            if (out[k] && n_max[k] == 0) first_bin[k] = w * 32 + __ffs(out[k]) - 1;
+            n_max[k] += __popc(out[k]);
+        }
+        *reinterpret_cast<uint4*>(cand + (long long)w * sn + i4) = make_uint4(out[0], out[1], out[2], out[3]);
     }
     int lab[4];
 #pragma unroll
