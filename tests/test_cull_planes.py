@@ -103,3 +103,17 @@ def test_extreme_or_broken_views_are_never_culled():
             fired += 1
             assert not vis[inside].any()
     assert fired > 20 and vis.any()
+    # mirrored intrinsics (negative focal lengths are legal inputs of the reference's formula)
+    for fx, fy in ((-800.0, 700.0), (650.0, -900.0), (-500.0, -500.0)):
+        cam = {"fx": fx, "fy": fy, "width": 640, "height": 480, "rotation": np.eye(3).tolist(), "position": [0.1, 0.2, -6.0]}
+        P = labeler.cull_planes(cam)
+        vis = oracle.project_many(pos, cam)[0] >= 0
+        fired = 0
+        for _ in range(300):
+            cc = p64[rng.integers(len(pos))]
+            d = np.linalg.norm(p64 - cc, axis=1)
+            inside = d <= 0.4
+            if _fires(P, cc, d[inside].max() * (1 + 1e-12)):
+                fired += 1
+                assert not vis[inside].any(), (fx, fy)
+        assert fired > 20 and vis.any(), (fx, fy)
