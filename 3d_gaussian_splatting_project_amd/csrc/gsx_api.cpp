@@ -124,7 +124,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->stage, &c->errflag,
-                           &c->cnt, &c->fv, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
+                           &c->cnt, &c->fv, &c->bcnt, &c->bcodes, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();
@@ -163,6 +163,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
     else if (k == "flat_project") c->opt_flat_project = value != 0;
     else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
+    else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)

@@ -117,6 +117,7 @@ struct Ctx {
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
+    int opt_batched_counts = 1; // > 255 views on one GPU: per-batch count planes + sparse tie pass instead of 16-bit planes
     int opt_seg_coarse = 1;    // keep a 4x4-coarsened level of every tiled map (views staged after the call)
     int opt_flat_project = 1;  // branchless projection block (exact divisions, one predicate at the end)
 
@@ -147,6 +148,7 @@ struct Ctx {
     bool planes_stale = false;  // planes hold a rewound run's votes; the next fresh flush overwrites them
     DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
     DevBuf keys, labels;        // [n_pad] int32
+    DevBuf bcnt, bcodes;        // > 255 views on one GPU: per-batch u8 count planes [S][bins][n_pad], tie codes u16 [S][n_pad]
     DevBuf cand, codes;         // exchange v3: candidate masks u32[8][sn] of this slab; tie codes u16[n_pad]
     bool labels_valid = false;
 

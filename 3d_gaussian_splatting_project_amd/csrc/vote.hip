@@ -1394,10 +1394,83 @@ int vote_labels_from_keys(Ctx* c, int32_t* labels_out) {
     return labels_to_host(c, labels_out);
 }
 
+FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
+
+// More than 255 views on one GPU (the reference's own cameras.json holds 311): the views are cut into S balanced
+// batches of <= 255 that play the ranks of exchange protocol v3 on a single device.  Every batch is one launch of the
+// fast u8-histogram walk (vote_fused_counts_kernel) into its own count plane; vote_slab_totals_kernel sums the S
+// planes per bin (unique maximum -> label, else a candidate mask); vote_tie_kernel walks each batch forward for the
+// tied Gaussians and vote_tie_resolve_kernel takes the earliest batch that voted a candidate = the earliest view,
+// which is the reference's first-inserted rule (dls.py:303).  Replaces the 16-bit count + first-view planes of
+// vote_flush() for this case (1.9 ms per 200 views at C3 sizes against 1.1 ms).
+static int vote_finalize_batched(Ctx* c, int32_t* labels_out) {
+    int rc = sync_views(c);
+    if (rc) return rc;
+    const int nv = (int)c->views.size();
+    const int S = (nv + kMaxBatch - 1) / kMaxBatch;
+    const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
+    GSX_HIP(c, c->bcnt.ensure(plane * S));
+    GSX_HIP(c, c->cand.ensure(sizeof(uint32_t) * kCandWords * (size_t)c->n_pad));
+    GSX_HIP(c, c->bcodes.ensure(sizeof(uint16_t) * (size_t)c->n_pad * S));
+    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)c->n_pad));
+    GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    if (c->n > 0) {
+        const int dm = div_mode(c);
+        auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+                 : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
+                 : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
+                 : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
+                                       : vote_fused_counts_kernel<kUnroll, kDivExact>;
+        FusedParams base = fused_params(c, 1);
+        const size_t lds = (size_t)kBlock * base.stride_dw * 4;
+        if ((rc = set_lds(c, k, lds))) return rc;
+        auto batch = [&](int s, FusedParams& p) {  // views [lo, hi) of batch s, sizes differ by at most one
+            const int lo = (int)((long long)nv * s / S), hi = (int)((long long)nv * (s + 1) / S);
+            p = base;
+            p.views = base.views + lo;
+            p.nviews = hi - lo;
+            if (p.cull) p.cull = base.cull + lo;
+        };
+        for (int s = 0; s < S; ++s) {
+            FusedParams p;
+            batch(s, p);
+            ProfScope ps(c, "vote_fused_counts");
+            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->bcnt.as<uint8_t>() + plane * s,
+                               (long long)c->n_pad);
+        }
+        GSX_HIP(c, hipGetLastError());
+        {
+            ProfScope ps(c, "vote_slab_totals");
+            hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(c->n_pad / 4)), dim3(kBlock), 0, c->stream,
+                               c->bcnt.as<uint8_t>(), S, c->bins, (long long)c->n_pad, c->keys.as<int>(), c->cand.as<uint32_t>());
+        }
+        for (int s = 0; s < S; ++s) {
+            FusedParams p;
+            batch(s, p);
+            ProfScope ps(c, "vote_tie");
+            hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, p, p.views, c->cand.as<uint32_t>(),
+                               (long long)c->n_pad, c->bcodes.as<uint16_t>() + (size_t)c->n_pad * s);
+        }
+        {
+            ProfScope ps(c, "vote_tie_resolve");
+            hipLaunchKernelGGL(vote_tie_resolve_kernel, dim3(grid_for(c->n_pad)), dim3(kBlock), 0, c->stream, c->bcodes.as<uint16_t>(), S,
+                               (long long)c->n_pad, c->keys.as<int>());
+        }
+        {
+            ProfScope ps(c, "vote_labels");
+            hipLaunchKernelGGL(unpermute_labels_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->keys.as<int>(),
+                               (long long)c->n, c->sorted ? c->perm.as<uint32_t>() : nullptr, c->labels.as<int>());
+        }
+        GSX_HIP(c, hipGetLastError());
+    }
+    return labels_to_host(c, labels_out);
+}
+
 int vote_finalize(Ctx* c, int32_t* labels_out) {
     if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_finalize before vote_begin");
     GSX_HIP(c, hipSetDevice(c->device));
     const int nv = (int)c->views.size();
+    if (c->n_flushed == 0 && nv > kMaxBatch && !c->local_codes && c->opt_batched_counts) return vote_finalize_batched(c, labels_out);
     if (c->n_flushed == 0 && nv <= kMaxBatch) {
         // single batch, nothing in the planes: labels come straight out of the fused kernel
         int rc = sync_views(c);
@@ -1446,7 +1519,7 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
 }
 
 // ---- exchange v3 host side ------------------------------------------------------------------------------------
-static FusedParams fused_params(Ctx* c, int stride_bytes_per_bin) {
+FusedParams fused_params(Ctx* c, int stride_bytes_per_bin) {
     FusedParams p{};
     p.x = c->x.as<float>();
     p.y = c->y.as<float>();

@@ -100,6 +100,9 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               blend -3 %, paid back by the extra ordering launches)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as strips of 16 pixel columns (16x8 pixels per 128-B line;
  *                               applies to the views staged after the call)
+ *   "batched_counts" (default 1) more than 255 views on one GPU: one fast u8-histogram launch per batch of <= 255 views
+ *                               into its own count plane, then the sparse tie pass of exchange protocol v3 across
+ *                               the batches (0: accumulate 16-bit count and first-view planes instead)
  *   "seg_coarse"   (default 1)  keep a second, 4x4-coarsened level of every strip-stored map (a cell holds the label
  *                               its 16 pixels share, or 255) and look a vote up there first; only lanes that hit a
  *                               mixed cell read the full-resolution map.  Same labels; a wave then touches ~3 cache

@@ -300,12 +300,39 @@ def test_wide_counters_and_multi_batch(ctx):
     segs = [rng.integers(-1, 4, size=(64, 96), dtype=np.int32) for _ in range(V)]
     sizes = [(96, 64)] * V
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
-    got = run_gpu(ctx, pos, cams, segs, sizes, n_classes=4).vote_finalize()
+    got = run_gpu(ctx, pos, cams, segs, sizes, n_classes=4).vote_finalize()     # batched count planes + tie pass
     assert np.array_equal(got, want)
+    ctx.set_option("batched_counts", 0)
+    ctx.vote_rewind()
+    assert np.array_equal(ctx.vote_finalize(), want)                            # 16-bit count + first-view planes
+    ctx.set_option("batched_counts", 1)
     cnt, fv = ctx.debug_planes(5)
     sh = oracle.NumpyVoteShard(pos, cams, segs, sizes, 4, 0, V)
     assert np.array_equal(cnt, sh.cnt[:, :n]) and np.array_equal(fv, sh.fv[:, :n])
     assert cnt.max() > 60           # counts beyond one 255-view batch's share were accumulated
+
+
+def test_more_than_255_views_on_one_gpu(gsx):
+    """311 views (the size of the reference's cameras.json), 150 classes, maps with few classes so that ties are common:
+    the batched path (2 batches of 155/156 views) against the oracle and against the 16-bit planes path; then 700 views
+    (3 batches) with every option that changes the kernel family."""
+    n = 60_000
+    for V, opts in ((311, {}), (700, {"seg_coarse": 0, "wave_cull": 0}), (256, {"flat_project": 0}), (311, {"spatial_sort": 0, "vote_unroll": 2})):
+        pos, cams, _ = scene.make_scene(n, V, 160, 96, config_id=31, convention="w2c")
+        segs = [scene.make_segmap(96, 160, 6, 9000 + v, n_sites=12, cell=int(1 + v % 4)) for v in range(V)]
+        sizes = [(160, 96)] * V
+        want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+        with gsx.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            got = run_gpu(c, pos, cams, segs, sizes, n_classes=6).vote_finalize()
+            assert np.array_equal(got, want), (V, opts)
+            c.vote_rewind()
+            assert np.array_equal(c.vote_finalize(), want), (V, opts, "again")   # re-run on the same context
+            c.set_option("batched_counts", 0)
+            c.vote_rewind()
+            assert np.array_equal(c.vote_finalize(), want), (V, opts, "planes")
+        assert len(np.unique(want)) > 3
 
 
 def test_view_sharding_exchange_on_one_gpu(gsx, ctx):
