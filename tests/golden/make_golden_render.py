@@ -5,7 +5,7 @@ own worker code under node (tools/make_golden_js.js) on a seeded synthetic 3DGS 
 Pins, byte for byte: processPlyBuffer (gs.js:464-585: importance order, 32-byte rows, u8
 quantisation), generateTexture (gs.js:286-357: 4*Sigma as truncated fp16), runSort (gs.js:417-462:
 16-bit counting sort incl. the dropped max-depth splat) and the matrices of gs.js:66-123.
-Build-container only.  Usage: python tools/make_golden_render.py
+Build-container only.  Usage: python tests/golden/make_golden_render.py
 """
 import base64
 import json
@@ -16,7 +16,7 @@ import tempfile
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 OUT = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised soak of the labeler against the oracle (GPU box): scenes large enough for whole waves to be culled,
 cameras inside and outside the scene, class maps with every mix of uniform and boundary cells, sizes that are not
-multiples of 4 / 16, random tuning options, single launch and planes path.  Usage: tools/soak.py SEED TRIALS"""
+multiples of 4 / 16, random tuning options, single launch and planes path.  Usage: tests/soak.py SEED TRIALS"""
 import importlib
 import os
 import sys
