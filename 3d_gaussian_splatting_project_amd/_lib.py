@@ -10,7 +10,7 @@ CSRC = os.path.join(_DIR, "csrc")
 
 GSX_OK = 0
 GSX_E_INVALID, GSX_E_HIP, GSX_E_STATE, GSX_E_RANGE, GSX_E_UNSUPPORTED, GSX_E_IO = -1, -2, -3, -4, -5, -6
-GSX_SEG_I32, GSX_SEG_I64, GSX_SEG_U8 = 0, 1, 2
+GSX_SEG_I32, GSX_SEG_I64, GSX_SEG_U8, GSX_SEG_U8_LABELS = 0, 1, 2, 3
 
 
 class GsxError(RuntimeError):
@@ -61,6 +61,10 @@ _SIGS = {
                                 C.c_int32]),
     "gsx_vote_view_device": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32]),
+    "gsx_vote_views_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32]),
+    "gsx_debug_host_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "gsx_vote_num_views": (C.c_int32, [C.c_void_p]),
     "gsx_vote_rewind": (C.c_int, [C.c_void_p]),
     "gsx_vote_finalize": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -80,6 +84,11 @@ _SIGS = {
     "gsx_vote_codes_device": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_int64)]),
     "gsx_vote_tie_resolve": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_vote_labels_from_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gsx_vote_export": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "gsx_vote_import": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gsx_vote_slab_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "gsx_host_threads": (C.c_int, [C.c_void_p]),
+    "gsx_profile_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_upload_splats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6),
     "gsx_upload_sh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

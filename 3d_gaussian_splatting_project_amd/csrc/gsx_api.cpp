@@ -123,11 +123,12 @@ void gsx_destroy(gsx_ctx* ctx) {
     (void)hipStreamSynchronize(c->stream);
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
-    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->stage, &c->errflag,
+    for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->errflag,
                            &c->cnt, &c->fv, &c->bcnt, &c->bcodes, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();
+    gsx::vote_release_host(c);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -165,6 +166,14 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
+    else if (k == "host_threads") {
+        if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
+        if ((int)value != c->opt_host_threads) {
+            delete c->workers;  // re-created with the new size at the next host-side hand-over
+            c->workers = nullptr;
+        }
+        c->opt_host_threads = (int)value;
+    }
     else if (k == "vote_unroll") {
         if (value != 2 && value != 4 && value != 8)
             return gsx::fail(c, GSX_E_INVALID, "set_option: vote_unroll must be 2, 4 or 8");
@@ -264,12 +273,22 @@ int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t 
 int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
                   int32_t seg_h, int32_t img_w, int32_t img_h) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_view(c, cam, seg, false, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return gsx::vote_view(c, cam, seg, seg_dtype, seg_w, seg_h, img_w, img_h);
 }
 int gsx_vote_view_device(gsx_ctx* ctx, const gsx_camera* cam, const void* seg_dev, int32_t seg_dtype, int32_t seg_w,
                          int32_t seg_h, int32_t img_w, int32_t img_h) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_view(c, cam, seg_dev, true, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return gsx::vote_views_device(c, 1, cam, &seg_dev, seg_dtype, seg_w, seg_h, img_w, img_h);
+}
+int gsx_vote_views_device(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, const void* const* segs_dev, int32_t seg_dtype,
+                          int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_views_device(c, n, cams, segs_dev, seg_dtype, seg_w, seg_h, img_w, img_h);
+}
+int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
+                        int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
+                        int32_t* bad) {
+    return gsx::debug_host_pack(seg, seg_dtype, w, h, n_classes, tiled, coarse, threads, out, out_cap, bytes, coarse_off, bad);
 }
 int32_t gsx_vote_num_views(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
@@ -356,6 +375,23 @@ int gsx_vote_tie_resolve(gsx_ctx* ctx, const void* recv_codes_dev) {
 int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
     return gsx::vote_labels_from_sorted(c, sorted_labels_dev, labels_out);
+}
+int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_export(c, reserve_bytes, blobs_out, pool_dev, pool_bytes);
+}
+int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
+                    const void* pool_all_dev, int64_t pool_all_bytes) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_import(c, n_parts, part_views, part_offsets, blobs, pool_all_dev, pool_all_bytes);
+}
+int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size) {
+    CTX_OR_FAIL(ctx);
+    return gsx::vote_slab_labels(c, slab, slabs, slab_size);
+}
+int gsx_host_threads(gsx_ctx* ctx) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    return c ? gsx::host_threads(c) : 0;
 }
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
@@ -459,6 +495,11 @@ int gsx_profile_reset(gsx_ctx* ctx) {
     gsx::prof_drain(c);
     c->prof_acc.clear();
     return GSX_OK;
+}
+const char* gsx_profile_name(gsx_ctx* ctx, int32_t index) {
+    Ctx* c = reinterpret_cast<Ctx*>(ctx);
+    if (!c || index < 0 || (size_t)index >= c->prof_names.size()) return nullptr;
+    return c->prof_names[(size_t)index].c_str();
 }
 int gsx_profile_get(gsx_ctx* ctx, const char* name, int64_t* launches, double* total_ms) {
     CTX_OR_FAIL(ctx);

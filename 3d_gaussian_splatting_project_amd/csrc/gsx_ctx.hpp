@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/gsx.h"
+#include "host_pack.hpp"
 
 namespace gsx {
 
@@ -87,6 +88,17 @@ struct alignas(64) ViewDesc {
 };
 static_assert(sizeof(ViewDesc) == 256 && offsetof(ViewDesc, wscale) == 192, "ViewDesc layout");
 
+// one slot of the pinned staging ring of gsx_vote_view (host maps): packed by the host workers, DMA'd to the pool
+struct PinSlot {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;  // recorded after the slot's H2D copy
+    bool busy = false;
+};
+static constexpr int kPinSlots = 4;
+static constexpr int kLabelChunks = 4;
+static constexpr int kNoBadView = 0x7f7f7f7f;  // errflag value meaning "every device-side map was in range"
+
 struct ProfEvent {
     int name_id;
     hipEvent_t start, stop;
@@ -140,8 +152,19 @@ struct Ctx {
     DevBuf d_views;
     DevBuf segpool;
     size_t seg_used = 0;
-    DevBuf stage;  // raw int32/int64 map staging for gsx_vote_view
-    DevBuf errflag;
+    DevBuf errflag;  // int: smallest view index whose device-side map held a label out of range (kNoBadView: none)
+    // host hand-over (vote.hip): worker pool, pinned ring for the maps, pinned landing zone for the labels
+    Workers* workers = nullptr;
+    int opt_host_threads = 0;  // 0: default_host_threads()
+    PinSlot ring[kPinSlots];
+    int ring_next = 0;
+    void* h_labels = nullptr;  // pinned: n int32 labels + one int (the error flag) land here before the caller's array
+    size_t h_labels_cap = 0;
+    hipEvent_t h_ev[kLabelChunks] = {nullptr, nullptr, nullptr, nullptr};
+    void* h_views = nullptr;   // pinned: view descriptors + culling planes on their way to d_views / d_cull
+    size_t h_views_cap = 0;
+    hipEvent_t h_views_ev = nullptr;
+    const void* pool_base = nullptr;  // gsx_vote_import: the maps live in a caller-owned gathered pool, not in segpool
     int n_flushed = 0;         // views [0, n_flushed) are already in the planes
     bool planes_valid = false;  // planes hold votes (zeroed at begin/rewind)
     bool planes_zero = false;   // planes are known to be all-zero
@@ -189,8 +212,17 @@ struct ProfScope {
 
 // vote.hip
 int vote_begin(Ctx* c, int n_classes, int first_view, int total_views);
-int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device, int seg_dtype, int seg_w,
-              int seg_h, int img_w, int img_h);
+int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int seg_w, int seg_h, int img_w, int img_h);
+int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* segs, int seg_dtype, int seg_w, int seg_h,
+                      int img_w, int img_h);
+int vote_export(Ctx* c, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes);
+int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
+                const void* pool_all_dev, int64_t pool_all_bytes);
+int vote_slab_labels(Ctx* c, int slab, int slabs, int64_t* slab_size);
+int host_threads(Ctx* c);
+void vote_release_host(Ctx* c);  // pinned buffers, events, worker pool (gsx_destroy)
+int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes, int tiled, int coarse, int threads,
+                    uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off, int32_t* bad);
 int vote_rewind(Ctx* c);
 int vote_finalize(Ctx* c, int32_t* labels_out);
 int vote_flush(Ctx* c);

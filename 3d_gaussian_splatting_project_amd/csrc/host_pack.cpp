@@ -1,0 +1,359 @@
+// host_pack.cpp — see host_pack.hpp.  Pure C++, built by g++ (AVX2 forms of the inner loops, chosen at run time).
+#include "host_pack.hpp"
+
+#include <sched.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+static inline void cpu_relax() { _mm_pause(); }
+#else
+static inline void cpu_relax() {}
+#endif
+
+namespace gsx {
+
+MapLayout map_layout(int w, int h, bool tiled, bool coarse) {
+    MapLayout L;
+    L.w = w;
+    L.h = h;
+    const size_t npix = (size_t)w * (size_t)h;
+    L.strip_bytes = tiled ? (h + 7) / 8 * 128 : 0;
+    L.fine_bytes = tiled ? (size_t)L.strip_bytes * (size_t)((w + 15) / 16) : npix + 4;
+    L.cw = (w + 3) / 4;
+    L.ch = (h + 3) / 4;
+    const bool c = tiled && coarse;
+    L.cstrip_bytes = c ? (L.ch + 7) / 8 * 128 : 0;
+    L.coarse_off = (L.fine_bytes + 255) / 256 * 256;
+    L.map_bytes = c ? L.coarse_off + (size_t)L.cstrip_bytes * (size_t)((L.cw + 15) / 16) : L.fine_bytes;
+    return L;
+}
+
+// ---- worker pool ---------------------------------------------------------------------------------------------------
+struct Workers::Impl {
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv;
+    std::atomic<uint64_t> generation{0};  // bumped once per run()
+    std::atomic<int> next{0}, done{0};
+    std::atomic<int> parts{0};
+    void (*fn)(void*, int) = nullptr;
+    void* arg = nullptr;
+    std::atomic<bool> stop{false};
+
+    void work() {
+        for (;;) {
+            const int p = next.fetch_add(1, std::memory_order_acq_rel);
+            if (p >= parts.load(std::memory_order_relaxed)) break;
+            fn(arg, p);
+            done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            // the calls of one labelling run arrive ~100 us apart: spin briefly before going to sleep
+            int spins = 0;
+            while (generation.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                if (++spins < 4000) {
+                    cpu_relax();
+                } else {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return generation.load(std::memory_order_acquire) != seen || stop.load(); });
+                }
+            }
+            if (stop.load()) return;
+            seen = generation.load(std::memory_order_acquire);
+            work();
+        }
+    }
+};
+
+Workers::Workers(int threads) : impl_(new Impl), nthreads_(threads < 1 ? 1 : threads) {
+    for (int i = 1; i < nthreads_; ++i) impl_->threads.emplace_back([this] { impl_->loop(); });
+}
+
+Workers::~Workers() {
+    {
+        std::lock_guard<std::mutex> lk(impl_->m);
+        impl_->stop.store(true);
+    }
+    impl_->cv.notify_all();
+    for (auto& t : impl_->threads) t.join();
+    delete impl_;
+}
+
+void Workers::run(int parts, void (*fn)(void*, int), void* arg) {
+    if (parts <= 0) return;
+    if (nthreads_ == 1 || parts == 1) {
+        for (int p = 0; p < parts; ++p) fn(arg, p);
+        return;
+    }
+    Impl& s = *impl_;
+    s.parts.store(parts, std::memory_order_relaxed);
+    s.fn = fn;
+    s.arg = arg;
+    s.done.store(0, std::memory_order_relaxed);
+    s.next.store(0, std::memory_order_release);  // publishes parts / fn / arg to a worker that claims a part
+    {
+        std::lock_guard<std::mutex> lk(s.m);  // pairs with the sleepers' predicate check
+        s.generation.fetch_add(1, std::memory_order_release);
+    }
+    s.cv.notify_all();
+    s.work();
+    while (s.done.load(std::memory_order_acquire) < parts) cpu_relax();
+    // A worker that woke late may still be on its way into work(): it either finds next >= parts and leaves, or
+    // (if the following run() has already reset `next`) claims a part of THAT run, whose fn / arg were published
+    // by the release store above.  Either way every part runs exactly once.
+}
+
+int default_host_threads() {
+    if (const char* e = std::getenv("GSX_HOST_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return v > 256 ? 256 : v;
+    }
+    int cpus = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+    if (cpus < 1) cpus = (int)std::thread::hardware_concurrency();
+    if (cpus < 1) cpus = 1;
+    return cpus > 16 ? 16 : cpus;
+}
+
+// ---- the narrowing copy --------------------------------------------------------------------------------------------
+// bin = label + ADD as an unsigned number: label -1 -> 0, anything below -1 wraps far above `bins`.
+// Rows<T, ADD>::run narrows `rows` rows of 16 pixels (source rows `pitch` elements apart) into rows*16 consecutive
+// bytes and returns non-zero if a bin >= bins was seen.  A scalar form for every dtype, AVX2 forms for the wide ones.
+template <typename T, unsigned ADD>
+static inline unsigned narrow_n(const T* __restrict__ src, int cnt, unsigned bins, uint8_t* __restrict__ out) {
+    unsigned bad = 0;
+    for (int k = 0; k < cnt; ++k) {
+        const uint64_t b = (uint64_t)(int64_t)src[k] + ADD;  // T = uint8_t: plain zero-extension
+        bad |= (unsigned)(b >= bins);
+        out[k] = (uint8_t)b;
+    }
+    return bad;
+}
+
+template <typename T, unsigned ADD>
+static unsigned rows16_scalar(const T* __restrict__ src, size_t pitch, int rows, unsigned bins, uint8_t* __restrict__ out) {
+    unsigned bad = 0;
+    for (int r = 0; r < rows; ++r) bad |= narrow_n<T, ADD>(src + (size_t)r * pitch, 16, bins, out + r * 16);
+    return bad;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static unsigned rows16_i32_avx2(const int32_t* __restrict__ src, size_t pitch, int rows,
+                                                                 unsigned bins, uint8_t* __restrict__ out) {
+    const __m256i one = _mm256_set1_epi32(1);
+    __m256i mx = _mm256_setzero_si256();
+    for (int r = 0; r < rows; ++r) {
+        const int32_t* p = src + (size_t)r * pitch;
+        __m256i a = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p)), one);
+        __m256i b = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 8)), one);
+        mx = _mm256_max_epu32(mx, _mm256_max_epu32(a, b));
+        // packus saturates, but a value it would change (> 255, or "negative" = below label -1) is flagged bad anyway
+        __m256i w = _mm256_permute4x64_epi64(_mm256_packus_epi32(a, b), 0xD8);  // u16: a0..7 | b0..7
+        __m128i q = _mm_packus_epi16(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + r * 16), q);
+    }
+    __m128i m = _mm_max_epu32(_mm256_castsi256_si128(mx), _mm256_extracti128_si256(mx, 1));
+    m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0x4E));
+    m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0xB1));
+    return (unsigned)_mm_cvtsi128_si32(m) >= bins ? 1u : 0u;
+}
+
+__attribute__((target("avx2"))) static unsigned rows16_i64_avx2(const int64_t* __restrict__ src, size_t pitch, int rows,
+                                                                 unsigned bins, uint8_t* __restrict__ out) {
+    const __m256i one = _mm256_set1_epi64x(1);
+    const __m256i idx = _mm256_setr_epi32(0, 2, 4, 6, 1, 3, 5, 7);  // low dwords first, high dwords second
+    __m256i mx = _mm256_setzero_si256(), hi_or = _mm256_setzero_si256();
+    for (int r = 0; r < rows; ++r) {
+        const int64_t* p = src + (size_t)r * pitch;
+        __m256i lo[2];
+        for (int h = 0; h < 2; ++h) {
+            __m256i a = _mm256_add_epi64(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 8 * h)), one);
+            __m256i b = _mm256_add_epi64(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 8 * h + 4)), one);
+            a = _mm256_permutevar8x32_epi32(a, idx);  // [lo a0..3 | hi a0..3]
+            b = _mm256_permutevar8x32_epi32(b, idx);
+            lo[h] = _mm256_permute2x128_si256(a, b, 0x20);                          // low dwords of 8 values
+            hi_or = _mm256_or_si256(hi_or, _mm256_permute2x128_si256(a, b, 0x31));  // any high dword set -> out of range
+            mx = _mm256_max_epu32(mx, lo[h]);
+        }
+        __m256i w = _mm256_permute4x64_epi64(_mm256_packus_epi32(lo[0], lo[1]), 0xD8);
+        __m128i q = _mm_packus_epi16(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1));
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + r * 16), q);
+    }
+    __m128i m = _mm_max_epu32(_mm256_castsi256_si128(mx), _mm256_extracti128_si256(mx, 1));
+    m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0x4E));
+    m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0xB1));
+    return ((unsigned)_mm_cvtsi128_si32(m) >= bins || !_mm256_testz_si256(hi_or, hi_or)) ? 1u : 0u;
+}
+// the coarse byte of the four 4x4 cells of one strip: rows r0..r3 are 64 consecutive bytes (16 pixels each)
+__attribute__((target("avx2"))) static uint32_t coarse_word_avx2(const uint8_t* __restrict__ q) {
+    const __m128i r0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q));
+    const __m128i r1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 16));
+    const __m128i r2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 32));
+    const __m128i r3 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 48));
+    const __m128i first = _mm_shuffle_epi8(r0, _mm_setr_epi8(0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8, 12, 12, 12, 12));
+    __m128i eq = _mm_and_si128(_mm_and_si128(_mm_cmpeq_epi8(r0, first), _mm_cmpeq_epi8(r1, first)),
+                               _mm_and_si128(_mm_cmpeq_epi8(r2, first), _mm_cmpeq_epi8(r3, first)));
+    eq = _mm_cmpeq_epi32(eq, _mm_set1_epi32(-1));                       // per cell: all 16 pixels equal the first
+    const __m128i val = _mm_blendv_epi8(_mm_set1_epi8((char)255), first, eq);
+    return (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(val, _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1)));
+}
+static const bool g_avx2 = __builtin_cpu_supports("avx2");
+#else
+static const bool g_avx2 = false;
+static uint32_t coarse_word_avx2(const uint8_t*) { return 0; }
+#endif
+
+template <typename T, unsigned ADD>
+static inline unsigned rows16(const T* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
+    return rows16_scalar<T, ADD>(src, pitch, rows, bins, out);
+}
+#if defined(__x86_64__)
+template <>
+inline unsigned rows16<int32_t, 1u>(const int32_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
+    return g_avx2 ? rows16_i32_avx2(src, pitch, rows, bins, out) : rows16_scalar<int32_t, 1u>(src, pitch, rows, bins, out);
+}
+template <>
+inline unsigned rows16<int64_t, 1u>(const int64_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
+    return g_avx2 ? rows16_i64_avx2(src, pitch, rows, bins, out) : rows16_scalar<int64_t, 1u>(src, pitch, rows, bins, out);
+}
+#endif
+
+struct PackJob {
+    const void* seg;
+    MapLayout L;
+    unsigned bins;
+    uint8_t* dst;
+    std::atomic<unsigned> bad{0};
+};
+
+// one band of 8 pixel rows = one 128-B line of every strip (and two rows of coarse cells)
+template <typename T, unsigned ADD>
+static void pack_band_tiled(PackJob* j, int band) {
+    const MapLayout L = j->L;  // by value: the u8 stores below may alias anything reached through a pointer
+    const unsigned bins = j->bins;
+    uint8_t* const dst = j->dst;
+    const T* seg = static_cast<const T*>(j->seg);
+    const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
+    const int strips = (L.w + 15) / 16;
+    unsigned bad = 0;
+    for (int s = 0; s < strips; ++s) {
+        const int x0 = s * 16;
+        const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
+        uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)y0 * 16;
+        if (cnt == 16) {
+            bad |= rows16<T, ADD>(seg + (size_t)y0 * L.w + x0, (size_t)L.w, y1 - y0, bins, line);
+        } else {
+            for (int y = y0; y < y1; ++y) {
+                uint8_t* o = line + (y - y0) * 16;
+                std::memset(o, 0, 16);
+                bad |= narrow_n<T, ADD>(seg + (size_t)y * L.w + x0, cnt, bins, o);
+            }
+        }
+        if (y1 - y0 < 8) std::memset(line + (y1 - y0) * 16, 0, (size_t)(8 - (y1 - y0)) * 16);  // rows past the map: defined bytes
+        if (L.cstrip_bytes) {
+            // coarse cells of this strip: 4 per cell row; a cell holds the bin its 16 pixels share, else 255
+            // (cells that stick out of the map are "mixed": the vote then reads the exact pixel)
+            for (int cyl = 0; cyl < 2; ++cyl) {
+                const int cy = band * 2 + cyl;
+                if (cy >= L.ch) break;
+                uint32_t word = 0xffffffffu;
+                if (cy * 4 + 4 <= L.h) {
+                    if (g_avx2 && cnt == 16) {
+                        word = coarse_word_avx2(line + cyl * 64);
+                    } else {
+                        uint32_t r[4][4];
+                        std::memcpy(r, line + cyl * 64, 64);
+                        word = 0;
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t same = (r[0][c] & 0xffu) * 0x01010101u;
+                            const bool uniform = x0 + 4 * c + 4 <= L.w && r[0][c] == same && r[1][c] == same && r[2][c] == same && r[3][c] == same;
+                            word |= (uniform ? (r[0][c] & 0xffu) : 255u) << (8 * c);
+                        }
+                    }
+                }
+                const int cx0 = s * 4;  // first cell of the strip
+                const int ncell = L.cw - cx0 >= 4 ? 4 : L.cw - cx0;
+                uint8_t* co = dst + L.coarse_off + (size_t)(cx0 >> 4) * L.cstrip_bytes + (cx0 & 15) + (size_t)cy * 16;
+                if (ncell == 4) std::memcpy(co, &word, 4);
+                else std::memcpy(co, &word, (size_t)ncell);
+            }
+        }
+    }
+    if (bad) j->bad.fetch_or(1u, std::memory_order_relaxed);
+}
+
+template <typename T, unsigned ADD>
+static void pack_band_rows(PackJob* j, int band) {  // row-major u8 map ("seg_tiled" = 0)
+    const MapLayout L = j->L;
+    const T* seg = static_cast<const T*>(j->seg);
+    const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
+    const size_t i0 = (size_t)y0 * L.w, i1 = (size_t)y1 * L.w;
+    const size_t full = (i1 - i0) / 16;
+    unsigned bad = full ? rows16<T, ADD>(seg + i0, 16, (int)full, j->bins, j->dst + i0) : 0u;
+    const size_t i = i0 + full * 16;
+    if (i < i1) bad |= narrow_n<T, ADD>(seg + i, (int)(i1 - i), j->bins, j->dst + i);
+    if (bad) j->bad.fetch_or(1u, std::memory_order_relaxed);
+}
+
+template <typename T, unsigned ADD>
+static void pack_part(void* arg, int band) {
+    PackJob* j = static_cast<PackJob*>(arg);
+    if (j->L.strip_bytes) pack_band_tiled<T, ADD>(j, band);
+    else pack_band_rows<T, ADD>(j, band);
+}
+
+int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst) {
+    PackJob j;
+    j.seg = seg;
+    j.L = L;
+    j.bins = (unsigned)bins;
+    j.dst = dst;
+    void (*fn)(void*, int) = seg_dtype == 0   ? pack_part<int32_t, 1u>
+                             : seg_dtype == 1 ? pack_part<int64_t, 1u>
+                             : seg_dtype == 2 ? pack_part<uint8_t, 0u>
+                                              : pack_part<uint8_t, 1u>;
+    const int bands = (L.h + 7) / 8;
+    // the coarse level's padding (cell rows / columns past the map) is never read; zero it so that a packed map is a
+    // function of the map alone (the all-gather of protocol v4 ships these bytes)
+    if (L.cstrip_bytes) std::memset(dst + L.coarse_off, 0, L.map_bytes - L.coarse_off);
+    if (L.coarse_off > L.fine_bytes && L.cstrip_bytes) std::memset(dst + L.fine_bytes, 0, L.coarse_off - L.fine_bytes);
+    if (pool) pool->run(bands, fn, &j);
+    else
+        for (int b = 0; b < bands; ++b) fn(&j, b);
+    if (!L.strip_bytes) std::memset(dst + (size_t)L.w * L.h, 0, 4);  // the row-major form's 4 bytes of slack
+    return j.bad.load() ? 1 : 0;
+}
+
+struct CopyJob {
+    char* dst;
+    const char* src;
+    size_t bytes, chunk;
+};
+static void copy_part(void* arg, int part) {
+    CopyJob* j = static_cast<CopyJob*>(arg);
+    const size_t lo = (size_t)part * j->chunk;
+    const size_t hi = lo + j->chunk < j->bytes ? lo + j->chunk : j->bytes;
+    if (lo < hi) std::memcpy(j->dst + lo, j->src + lo, hi - lo);
+}
+void host_copy(Workers* pool, void* dst, const void* src, size_t bytes) {
+    if (!pool || bytes < ((size_t)1 << 20)) {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    CopyJob j{static_cast<char*>(dst), static_cast<const char*>(src), bytes, (size_t)256 << 10};
+    pool->run((int)((bytes + j.chunk - 1) / j.chunk), copy_part, &j);
+}
+
+}  // namespace gsx

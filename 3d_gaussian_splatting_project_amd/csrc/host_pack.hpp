@@ -1,0 +1,51 @@
+// Host side of the segmentation-map hand-over (gsx_vote_view with a HOST pointer): a small worker pool and the
+// dtype-narrowing copy into the pinned staging ring.  Pure C++ (no HIP): compiled by g++.
+//
+// A map must cross PCIe; before that it must be copied out of the caller's pageable buffer into pinned memory
+// anyway.  That one pass over the int32 / int64 labels (dls.py:124,142,158) writes the library's on-device form
+// directly — u8 bins (label + 1) in strips of 16 pixel columns plus the 4x4-coarsened level — so that 2.2 MB
+// instead of 8.3 MB per 1080p map go over the link and the GPU has nothing left to do but the DMA.  This is data
+// marshalling for the boundary, not a CPU path of the labeler: projection, votes and arg-max exist in HIP only.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace gsx {
+
+// Geometry of one packed map inside the seg pool (shared by the host packer, the device packer and vote_view).
+struct MapLayout {
+    int w = 0, h = 0;
+    int strip_bytes = 0;    // bytes per strip of 16 pixel columns: rows padded to a multiple of 8, 16 B per row; 0 = row-major
+    int cstrip_bytes = 0;   // same for the coarse level (strips of 16 cells = 64 pixel columns); 0 = no coarse level
+    int cw = 0, ch = 0;     // coarse cells per row / column
+    size_t fine_bytes = 0;  // bytes of the full-resolution level
+    size_t coarse_off = 0;  // offset of the coarse level from the map's start (256-B aligned)
+    size_t map_bytes = 0;   // total
+};
+MapLayout map_layout(int w, int h, bool tiled, bool coarse);
+
+// Fork-join pool: run(n, fn, arg) calls fn(arg, part) for part in [0, n) on the pool's threads and the caller.
+class Workers {
+public:
+    explicit Workers(int threads);  // total parallelism including the calling thread; >= 1
+    ~Workers();
+    Workers(const Workers&) = delete;
+    Workers& operator=(const Workers&) = delete;
+    int threads() const { return nthreads_; }
+    void run(int parts, void (*fn)(void*, int), void* arg);
+
+private:
+    struct Impl;
+    Impl* impl_;
+    int nthreads_;
+};
+int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HOST_THREADS
+
+// seg dtype codes as in gsx.h: 0 = int32, 1 = int64, 2 = u8 holding label+1, 3 = u8 holding the label.
+// Writes the packed map (layout L) at dst; returns 0, or 1 if a label lies outside [-1, bins-2].
+// `pool` may be nullptr (single thread).
+int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst);
+// out = in, split over the pool (D2H epilogue: pinned -> the caller's pageable array)
+void host_copy(Workers* pool, void* dst, const void* src, size_t bytes);
+
+}  // namespace gsx

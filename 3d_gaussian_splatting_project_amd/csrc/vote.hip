@@ -31,8 +31,10 @@
 //   order) is earliest among the max-count labels is the last one to do so.  See DESIGN.md §3.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <new>
 
 #include <type_traits>
 
@@ -312,57 +314,78 @@ __device__ __forceinline__ unsigned logical_block(unsigned b, unsigned nwg, int 
 }
 
 // -------------------------------------------------------------------------------------------------
-// seg-map packing: int32/int64/u8 host dtype -> u8 bin index (label+1), with range validation
+// seg-map packing on the device (gsx_vote_view_device / gsx_vote_views_device): ONE pass over the int32 / int64 /
+// u8 map writes both levels of the library's form — the u8 bins (label + 1) in strips of 16 pixel columns and the
+// 4x4-coarsened level (a cell = the bin its 16 pixels share, 255 where they differ or the cell sticks out of the
+// map) — and validates the label range.  One thread = one 4x4 cell: four 16-byte loads (int32), four u32 stores
+// (the four lanes of a strip write 64 contiguous bytes) and one coarse byte.  Up to kPackBatch maps of one geometry
+// per launch (blockIdx.y): a 1080p map is 8 MB, i.e. ~2 us of HBM time, less than a launch.
 // -------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kBlock) void seg_pack_kernel(const T* __restrict__ in, uint8_t* __restrict__ out, int w,
-                                                          int h, int groups_per_row, int tiles_w, int bins,
-                                                          int* __restrict__ err) {
-    // one thread = 4 horizontally adjacent pixels of one row: 16 B (int32) in, one aligned u32 out
-    const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const int y = (int)(q / groups_per_row);
-    if (y >= h) return;
-    const int x0 = (int)(q % groups_per_row) * 4;
-    const T* row = in + (long long)y * w;
-    int bad = 0;
-    uint32_t packed = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (x0 + k < w) {
-            const long long b = (long long)row[x0 + k] + (sizeof(T) == 1 ? 0 : 1);
-            bad |= (b < 0) | (b >= bins);
-            packed |= (uint32_t)(b & 0xff) << (8 * k);
-        }
-    }
-    long long o;
-    if (tiles_w) o = (long long)(x0 >> 4) * tiles_w + ((long long)y << 4) + (x0 & 15);  // tiles_w: bytes per 16-column strip
-    else o = (long long)y * w + x0;
-    if (tiles_w || (((w & 3) == 0))) {
-        *reinterpret_cast<uint32_t*>(out + o) = packed;  // tiled rows are 16 B, maps start 256-B aligned
-    } else {
-        for (int k = 0; k < 4 && x0 + k < w; ++k) out[o + k] = (uint8_t)(packed >> (8 * k));
-    }
-    if (bad) atomicOr(err, 1);
-}
+static constexpr int kPackBatch = 16;
+struct PackArgs {
+    const void* src[kPackBatch];
+    uint8_t* dst[kPackBatch];
+    int view[kPackBatch];  // index reported through `err` when the map holds a label outside [-1, bins-2]
+    int w, h, strip_bytes, cstrip_bytes, cw, ch, bins;
+    unsigned coarse_off;
+    int* err;              // atomicMin of the offending view indices (INT_MAX = none)
+};
 
-// coarse level of a strip-stored map: one thread = one 4x4 cell; 255 = "the 16 pixels differ" (or the cell sticks
-// out of the map), otherwise their common bin.  Same strip layout one level up (16 cells x 8 cell rows per line).
-__global__ __launch_bounds__(kBlock) void seg_coarse_kernel(const uint8_t* __restrict__ fine, uint8_t* __restrict__ coarse,
-                                                            int w, int h, int strip_bytes, int cstrip_bytes, int cw, int ch) {
+template <typename T, int ADD, bool VEC>
+__global__ __launch_bounds__(kBlock) void seg_pack_fused_kernel(PackArgs a) {
     const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
-    const int cy = (int)(q / cw), cx = (int)(q % cw);
-    if (cy >= ch) return;
+    const int cy = (int)(q / a.cw), cx = (int)(q % a.cw);
+    if (cy >= a.ch) return;
+    const int job = blockIdx.y;
+    const T* __restrict__ in = static_cast<const T*>(a.src[job]);
+    uint8_t* __restrict__ out = a.dst[job];
     const int x0 = cx * 4, y0 = cy * 4;
-    uint32_t value = 255;
-    if (x0 + 4 <= w && y0 + 4 <= h) {
-        const uint8_t* p = fine + (long long)(x0 >> 4) * strip_bytes + (x0 & 15) + ((long long)y0 << 4);
-        const uint32_t r0 = *reinterpret_cast<const uint32_t*>(p);
-        const uint32_t same = (r0 & 0xffu) * 0x01010101u;
-        const bool uniform = r0 == same && *reinterpret_cast<const uint32_t*>(p + 16) == same &&
-                             *reinterpret_cast<const uint32_t*>(p + 32) == same && *reinterpret_cast<const uint32_t*>(p + 48) == same;
-        if (uniform) value = r0 & 0xffu;
+    const unsigned bins = (unsigned)a.bins;
+    unsigned bad = 0;
+    uint32_t rows[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int y = y0 + r;
+        uint32_t packed = 0;
+        if (y < a.h) {
+            const T* row = in + (long long)y * a.w + x0;
+            T v[4];
+            bool have[4];
+            if (VEC) {  // host checked: w % 4 == 0 and a 16-byte aligned base, so x0 + 4 <= w and the vector is aligned
+                typedef T vec4 __attribute__((ext_vector_type(4)));
+                const vec4 t = *reinterpret_cast<const vec4*>(row);
+                v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+                have[0] = have[1] = have[2] = have[3] = true;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    have[k] = x0 + k < a.w;
+                    v[k] = have[k] ? row[k] : (T)0;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long b = (unsigned long long)(long long)v[k] + (unsigned)ADD;  // label -2 wraps far above bins
+                bad |= (unsigned)(have[k] & (b >= bins));
+                packed |= (have[k] ? (uint32_t)(b & 0xffu) : 0u) << (8 * k);  // columns past the edge: bin 0
+            }
+            if (a.strip_bytes) {
+                *reinterpret_cast<uint32_t*>(out + (long long)(x0 >> 4) * a.strip_bytes + ((long long)y << 4) + (x0 & 15)) = packed;
+            } else {
+                const long long o = (long long)y * a.w + x0;
+                if (VEC) *reinterpret_cast<uint32_t*>(out + o) = packed;
+                else
+                    for (int k = 0; k < 4 && x0 + k < a.w; ++k) out[o + k] = (uint8_t)(packed >> (8 * k));
+            }
+        }
+        rows[r] = packed;
     }
-    coarse[(long long)(cx >> 4) * cstrip_bytes + (cx & 15) + ((long long)cy << 4)] = (uint8_t)value;
+    if (a.cstrip_bytes) {
+        const uint32_t same = (rows[0] & 0xffu) * 0x01010101u;
+        const bool uniform = x0 + 4 <= a.w && y0 + 4 <= a.h && rows[0] == same && rows[1] == same && rows[2] == same && rows[3] == same;
+        out[a.coarse_off + (long long)(cx >> 4) * a.cstrip_bytes + (cx & 15) + ((long long)cy << 4)] = uniform ? (uint8_t)(rows[0] & 0xffu) : (uint8_t)255;
+    }
+    if (bad) atomicMin(a.err, a.view[job]);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1013,6 +1036,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->n_pad = c->sn * c->slabs;
     c->views.clear();
     c->views_dirty = true;
+    c->pool_base = nullptr;
     c->seg_used = 0;
     c->n_flushed = 0;
     c->planes_valid = false;
@@ -1020,7 +1044,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->planes_stale = false;
     c->labels_valid = false;
     GSX_HIP(c, c->errflag.ensure(sizeof(int)));
-    GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
+    GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0x7f, sizeof(int), c->stream));  // kNoBadView
     c->vote_begun = true;
     return GSX_OK;
 }
@@ -1045,84 +1069,170 @@ static int pool_reserve(Ctx* c, size_t need) {
     return GSX_OK;
 }
 
-int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, bool seg_on_device, int seg_dtype, int seg_w, int seg_h,
-              int img_w, int img_h) {
-    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_view before vote_begin");
-    if (!cam || !seg) return fail(c, GSX_E_INVALID, "vote_view: NULL argument");
+// ---- seg-map hand-over ------------------------------------------------------------------------------------------
+// Common front part of gsx_vote_view / gsx_vote_views_device: argument checks, the map's layout, room in the pool.
+static int view_prologue(Ctx* c, const char* who, const void* cams, const void* seg, int n, int seg_dtype, int seg_w, int seg_h,
+                         int img_w, int img_h, MapLayout& L) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "%s before vote_begin", who);
+    if (!cams || !seg) return fail(c, GSX_E_INVALID, "%s: NULL argument", who);
     if (seg_w < 1 || seg_h < 1 || img_w < 1 || img_h < 1)
-        return fail(c, GSX_E_INVALID, "vote_view: sizes must be positive (seg %dx%d, image %dx%d)", seg_w, seg_h, img_w,
-                    img_h);
+        return fail(c, GSX_E_INVALID, "%s: sizes must be positive (seg %dx%d, image %dx%d)", who, seg_w, seg_h, img_w, img_h);
     if (seg_w > 65535 || seg_h > 65535)  // in-map byte offsets are 32-bit, row products use 24-bit multiplies
-        return fail(c, GSX_E_RANGE, "vote_view: segmentation map %dx%d exceeds 65535 pixels a side", seg_w, seg_h);
-    if (seg_dtype != GSX_SEG_I32 && seg_dtype != GSX_SEG_I64 && seg_dtype != GSX_SEG_U8)
-        return fail(c, GSX_E_INVALID, "vote_view: unknown seg_dtype %d", seg_dtype);
-    if (c->first_view + (int)c->views.size() >= c->total_views)
-        return fail(c, GSX_E_RANGE, "vote_view: more views than total_views=%d announced at vote_begin", c->total_views);
-    if (c->local_codes && (int)c->views.size() >= kMaxBatch)
-        return fail(c, GSX_E_RANGE, "vote_view: the all-to-all exchange keeps 8-bit per-rank counters: at most %d views per rank",
+        return fail(c, GSX_E_RANGE, "%s: segmentation map %dx%d exceeds 65535 pixels a side", who, seg_w, seg_h);
+    if (seg_dtype != GSX_SEG_I32 && seg_dtype != GSX_SEG_I64 && seg_dtype != GSX_SEG_U8 && seg_dtype != GSX_SEG_U8_LABELS)
+        return fail(c, GSX_E_INVALID, "%s: unknown seg_dtype %d", who, seg_dtype);
+    if (c->first_view + (int)c->views.size() + n > c->total_views)
+        return fail(c, GSX_E_RANGE, "%s: more views than total_views=%d announced at vote_begin", who, c->total_views);
+    if (c->local_codes && (int)c->views.size() + n > kMaxBatch)
+        return fail(c, GSX_E_RANGE, "%s: the all-to-all exchange keeps 8-bit per-rank counters: at most %d views per rank", who,
                     kMaxBatch);
     GSX_HIP(c, hipSetDevice(c->device));
+    // bin 255 must be free to mean "mixed" in the coarse level
+    L = map_layout(seg_w, seg_h, c->opt_seg_tiled != 0, c->opt_seg_coarse && c->bins <= 255);
+    if (L.map_bytes > 0xffffffffull) return fail(c, GSX_E_RANGE, "%s: segmentation map %dx%d exceeds 4 GiB", who, seg_w, seg_h);
+    const size_t stride = (L.map_bytes + 255) / 256 * 256;  // 256-B aligned maps
+    const size_t off = (c->seg_used + 255) / 256 * 256;
+    size_t need = off + stride * (size_t)n;
+    if (c->views.empty()) {
+        // first view of a run: room for all announced views of this geometry at once (capped), so that the pool is
+        // not re-allocated and copied while maps stream in
+        const size_t all = stride * (size_t)(c->total_views - c->first_view);
+        need = std::max(need, std::min(all, (size_t)32 << 30));
+    }
+    return pool_reserve(c, need);
+}
 
-    const long long npix = (long long)seg_w * seg_h;
-    const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
-    const size_t off = (c->seg_used + 255) / 256 * 256;  // 256-B aligned maps
-    // "tiled" maps are stored as strips of 16 columns; tiles_w = bytes per strip (rows padded to a multiple of 8)
-    const int tiles_w = c->opt_seg_tiled ? (seg_h + 7) / 8 * 128 : 0;
-    const size_t fine_bytes = tiles_w ? (size_t)tiles_w * (size_t)((seg_w + 15) / 16) : (size_t)npix + 4;
-    // coarse level (4x4 pixels per cell, same strip layout); bin 255 must be free to mean "mixed"
-    const bool coarse = tiles_w && c->opt_seg_coarse && c->bins <= 255;
-    const int cw = (seg_w + 3) / 4, ch = (seg_h + 3) / 4;
-    const int ctiles = coarse ? (ch + 7) / 8 * 128 : 0;
-    const size_t coarse_off = (fine_bytes + 255) / 256 * 256;
-    const size_t map_bytes = coarse ? coarse_off + (size_t)ctiles * (size_t)((cw + 15) / 16) : fine_bytes;
-    if (map_bytes > 0xffffffffull)
-        return fail(c, GSX_E_RANGE, "vote_view: segmentation map %dx%d exceeds 4 GiB", seg_w, seg_h);
-    int rc = pool_reserve(c, off + map_bytes);
-    if (rc) return rc;
-    const void* src = seg;
-    if (!seg_on_device) {
-        GSX_HIP(c, c->stage.ensure(esz * npix));
-        GSX_HIP(c, hipMemcpyAsync(c->stage.p, seg, esz * npix, hipMemcpyHostToDevice, c->stream));
-        src = c->stage.p;
-    }
-    uint8_t* dst = c->segpool.as<uint8_t>() + off;
-    const int groups = (seg_w + 3) / 4;
-    const unsigned grid = grid_for((long long)groups * seg_h);
-    {
-        ProfScope ps(c, "seg_pack");
-        if (seg_dtype == GSX_SEG_I32)
-            hipLaunchKernelGGL(seg_pack_kernel<int32_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int32_t*)src, dst,
-                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
-        else if (seg_dtype == GSX_SEG_I64)
-            hipLaunchKernelGGL(seg_pack_kernel<int64_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const int64_t*)src, dst,
-                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
-        else
-            hipLaunchKernelGGL(seg_pack_kernel<uint8_t>, dim3(grid), dim3(kBlock), 0, c->stream, (const uint8_t*)src, dst,
-                               seg_w, seg_h, groups, tiles_w, c->bins, c->errflag.as<int>());
-    }
-    if (coarse) {
-        ProfScope ps(c, "seg_coarse");
-        hipLaunchKernelGGL(seg_coarse_kernel, dim3(grid_for((long long)cw * ch)), dim3(kBlock), 0, c->stream, dst,
-                           dst + coarse_off, seg_w, seg_h, tiles_w, ctiles, cw, ch);
-    }
-    GSX_HIP(c, hipGetLastError());
-    int bad = 0;
-    GSX_HIP(c, hipMemcpyAsync(&bad, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    if (bad) {
-        GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0, sizeof(int), c->stream));
-        return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
-    }
+static void push_view(Ctx* c, const gsx_camera* cam, const MapLayout& L, size_t off, int img_w, int img_h) {
     ViewDesc vd;
-    fill_view_desc(vd, cam, seg_w, seg_h, img_w, img_h);
+    fill_view_desc(vd, cam, L.w, L.h, img_w, img_h);
     vd.seg_off = (long long)off;
-    vd.seg_row_bytes = tiles_w;
-    vd.coarse_row_bytes = ctiles;
-    vd.coarse_delta = (unsigned)coarse_off;
+    vd.seg_row_bytes = L.strip_bytes;
+    vd.coarse_row_bytes = L.cstrip_bytes;
+    vd.coarse_delta = (unsigned)L.coarse_off;
     c->views.push_back(vd);
     c->views_dirty = true;
-    c->seg_used = off + map_bytes;
+    c->seg_used = off + L.map_bytes;
     c->labels_valid = false;
+}
+
+static Workers* host_workers(Ctx* c) {
+    if (!c->workers) c->workers = new (std::nothrow) Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads());
+    return c->workers;  // nullptr (out of memory): single-threaded packing
+}
+
+// Host map: the worker threads narrow it into the next slot of the pinned ring (u8 strips + coarse level, range
+// checked on the way: an out-of-range label fails THIS call), one asynchronous DMA moves the packed map into the
+// pool.  No kernel, no synchronisation; the call returns as soon as the caller's buffer has been read.
+int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int seg_w, int seg_h, int img_w, int img_h) {
+    MapLayout L;
+    int rc = view_prologue(c, "vote_view", cam, seg, 1, seg_dtype, seg_w, seg_h, img_w, img_h, L);
+    if (rc) return rc;
+    PinSlot& slot = c->ring[c->ring_next];
+    if (slot.busy) {
+        GSX_HIP(c, hipEventSynchronize(slot.ev));
+        slot.busy = false;
+    }
+    if (slot.cap < L.map_bytes) {
+        if (slot.p) GSX_HIP(c, hipHostFree(slot.p));
+        slot.p = nullptr;
+        slot.cap = 0;
+        const size_t cap = (L.map_bytes + ((size_t)1 << 20) - 1) >> 20 << 20;
+        GSX_HIP(c, hipHostMalloc(&slot.p, cap, hipHostMallocDefault));
+        slot.cap = cap;
+    }
+    if (!slot.ev) GSX_HIP(c, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    if (host_pack_map(host_workers(c), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(slot.p)))
+        return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
+    const size_t off = (c->seg_used + 255) / 256 * 256;
+    GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + off, slot.p, L.map_bytes, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipEventRecord(slot.ev, c->stream));
+    slot.busy = true;
+    c->ring_next = (c->ring_next + 1) % kPinSlots;
+    push_view(c, cam, L, off, img_w, img_h);
+    return GSX_OK;
+}
+
+// Device maps (all of one geometry and dtype): kPackBatch maps per launch of the fused pack kernel.  Nothing is
+// read back: a label out of range is recorded on the device and reported by the call that hands out the labels.
+int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* segs, int seg_dtype, int seg_w, int seg_h,
+                      int img_w, int img_h) {
+    if (n <= 0) return n == 0 ? GSX_OK : fail(c, GSX_E_INVALID, "vote_views_device: n < 0");
+    MapLayout L;
+    int rc = view_prologue(c, "vote_views_device", cams, segs, n, seg_dtype, seg_w, seg_h, img_w, img_h, L);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i)
+        if (!segs[i]) return fail(c, GSX_E_INVALID, "vote_views_device: map %d is NULL", i);
+    const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
+    const long long cells = (long long)L.cw * L.ch;
+    for (int i0 = 0; i0 < n; i0 += kPackBatch) {
+        const int m = std::min(kPackBatch, n - i0);
+        PackArgs a{};
+        bool vec = seg_w % 4 == 0;
+        size_t off = 0;
+        for (int k = 0; k < m; ++k) {
+            off = (c->seg_used + 255) / 256 * 256;
+            a.src[k] = segs[i0 + k];
+            a.dst[k] = c->segpool.as<uint8_t>() + off;
+            a.view[k] = c->first_view + (int)c->views.size();
+            vec = vec && reinterpret_cast<uintptr_t>(segs[i0 + k]) % (4 * esz) == 0;
+            push_view(c, cams + i0 + k, L, off, img_w, img_h);
+        }
+        a.w = L.w, a.h = L.h, a.strip_bytes = L.strip_bytes, a.cstrip_bytes = L.cstrip_bytes, a.cw = L.cw, a.ch = L.ch;
+        a.bins = c->bins;
+        a.coarse_off = (unsigned)L.coarse_off;
+        a.err = c->errflag.as<int>();
+        using K = void (*)(PackArgs);
+        static const K table[4][2] = {{seg_pack_fused_kernel<int32_t, 1, false>, seg_pack_fused_kernel<int32_t, 1, true>},
+                                      {seg_pack_fused_kernel<int64_t, 1, false>, seg_pack_fused_kernel<int64_t, 1, true>},
+                                      {seg_pack_fused_kernel<uint8_t, 0, false>, seg_pack_fused_kernel<uint8_t, 0, true>},
+                                      {seg_pack_fused_kernel<uint8_t, 1, false>, seg_pack_fused_kernel<uint8_t, 1, true>}};
+        ProfScope ps(c, "seg_pack");
+        hipLaunchKernelGGL(table[seg_dtype][vec ? 1 : 0], dim3(grid_for(cells), m), dim3(kBlock), 0, c->stream, a);
+        GSX_HIP(c, hipGetLastError());
+    }
+    return GSX_OK;
+}
+
+int host_threads(Ctx* c) {
+    Workers* w = host_workers(c);
+    return w ? w->threads() : 1;
+}
+
+void vote_release_host(Ctx* c) {
+    for (PinSlot& s : c->ring) {
+        if (s.ev) (void)hipEventDestroy(s.ev);
+        if (s.p) (void)hipHostFree(s.p);
+        s = PinSlot{};
+    }
+    for (hipEvent_t& e : c->h_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    if (c->h_labels) (void)hipHostFree(c->h_labels);
+    c->h_labels = nullptr;
+    c->h_labels_cap = 0;
+    if (c->h_views_ev) (void)hipEventDestroy(c->h_views_ev);
+    c->h_views_ev = nullptr;
+    if (c->h_views) (void)hipHostFree(c->h_views);
+    c->h_views = nullptr;
+    c->h_views_cap = 0;
+    delete c->workers;
+    c->workers = nullptr;
+}
+
+// test hook, host only: the packed form of one map exactly as gsx_vote_view stages it
+int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes, int tiled, int coarse, int threads,
+                    uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off, int32_t* bad) {
+    if (!seg || w < 1 || h < 1 || w > 65535 || h > 65535 || n_classes < 1 || n_classes > 255 || seg_dtype < 0 || seg_dtype > 3)
+        return fail(nullptr, GSX_E_INVALID, "debug_host_pack: bad arguments");
+    const MapLayout L = map_layout(w, h, tiled != 0, coarse != 0 && n_classes + 1 <= 255);
+    if (bytes) *bytes = (int64_t)L.map_bytes;
+    if (coarse_off) *coarse_off = L.cstrip_bytes ? (int64_t)L.coarse_off : -1;
+    if (!out) return GSX_OK;
+    if (out_cap < (int64_t)L.map_bytes) return fail(nullptr, GSX_E_INVALID, "debug_host_pack: output buffer too small");
+    Workers pool(threads > 0 ? threads : 1);
+    const int b = host_pack_map(&pool, seg, seg_dtype, L, n_classes + 1, out);
+    if (bad) *bad = b;
     return GSX_OK;
 }
 
@@ -1192,38 +1302,53 @@ void debug_cull_planes(const gsx_camera* cam, double* out) {
     cull_planes(vd, out);
 }
 
+// Host descriptors -> device: the map's absolute address goes into the device copy (one scalar add less per view
+// and wave), the culling planes are derived here.  Staged through pinned memory owned by the ctx and guarded by an
+// event, so nothing waits for the stream: the maps that vote_view queued keep flowing while this is prepared.
 static int sync_views(Ctx* c) {
     if (!c->views_dirty) return GSX_OK;
-    const size_t bytes = sizeof(ViewDesc) * (c->views.empty() ? 1 : c->views.size());
+    const size_t nv = c->views.size();
+    const size_t bytes = sizeof(ViewDesc) * (nv ? nv : 1);
     GSX_HIP(c, c->d_views.ensure(bytes));
-    c->views_simple = !c->views.empty();
+    c->views_simple = nv != 0;
     c->views_coarse = c->views_simple;
-    if (!c->views.empty()) {
-        // device copy: seg_off becomes the absolute address of the map (one scalar add less per view and wave)
-        std::vector<ViewDesc> dev(c->views);
-        const long long base = (long long)reinterpret_cast<uintptr_t>(c->segpool.p);
-        for (ViewDesc& v : dev) {
+    if (nv) {
+        const int pitch = (int)((nv + 63) / 64 * 64);
+        const size_t plane_doubles = (size_t)kCullStride * kCullPlanes * pitch;
+        const size_t need = bytes + sizeof(double) * plane_doubles;
+        if (c->h_views_ev) GSX_HIP(c, hipEventSynchronize(c->h_views_ev));  // the previous upload has left the buffer
+        else GSX_HIP(c, hipEventCreateWithFlags(&c->h_views_ev, hipEventDisableTiming));
+        if (c->h_views_cap < need) {
+            if (c->h_views) GSX_HIP(c, hipHostFree(c->h_views));
+            c->h_views = nullptr;
+            c->h_views_cap = 0;
+            GSX_HIP(c, hipHostMalloc(&c->h_views, need * 2, hipHostMallocDefault));
+            c->h_views_cap = need * 2;
+        }
+        ViewDesc* dev = static_cast<ViewDesc*>(c->h_views);
+        double* planes = reinterpret_cast<double*>(static_cast<char*>(c->h_views) + bytes);
+        std::memset(planes, 0, sizeof(double) * plane_doubles);
+        const long long base = (long long)reinterpret_cast<uintptr_t>(c->pool_base ? c->pool_base : c->segpool.p);
+        for (size_t i = 0; i < nv; ++i) {
+            ViewDesc& v = dev[i];
+            v = c->views[i];
             v.seg_off += base;
             c->views_simple = c->views_simple && v.unit_scale && v.seg_row_bytes;
             c->views_coarse = c->views_coarse && v.coarse_row_bytes;
-        }
-        GSX_HIP(c, hipMemcpyAsync(c->d_views.p, dev.data(), sizeof(ViewDesc) * dev.size(), hipMemcpyHostToDevice, c->stream));
-        // culling planes, plane-component-major so that lane l reads view l with unit stride
-        const int pitch = (int)((dev.size() + 63) / 64 * 64);
-        std::vector<double> planes((size_t)kCullStride * kCullPlanes * pitch, 0.0);
-        for (size_t i = 0; i < dev.size(); ++i) {
+            // culling planes, plane-component-major so that lane l reads view l with unit stride
             double pl[kCullStride * kCullPlanes];
-            cull_planes(dev[i], pl);
+            cull_planes(v, pl);
             for (int k = 0; k < kCullStride * kCullPlanes; ++k) planes[(size_t)k * pitch + i] = pl[k];
         }
-        GSX_HIP(c, c->d_cull.ensure(sizeof(double) * planes.size()));
-        GSX_HIP(c, hipMemcpyAsync(c->d_cull.p, planes.data(), sizeof(double) * planes.size(), hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(c, c->d_cull.ensure(sizeof(double) * plane_doubles));
+        GSX_HIP(c, hipMemcpyAsync(c->d_views.p, dev, bytes, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(c, hipMemcpyAsync(c->d_cull.p, planes, sizeof(double) * plane_doubles, hipMemcpyHostToDevice, c->stream));
+        GSX_HIP(c, hipEventRecord(c->h_views_ev, c->stream));
         c->cull_pitch = pitch;
         if (!c->d_cull_tally.p) {
             GSX_HIP(c, c->d_cull_tally.ensure(sizeof(unsigned long long)));
             GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof(unsigned long long), c->stream));
         }
-        GSX_HIP(c, hipStreamSynchronize(c->stream));  // `dev` and `planes` die here
     }
     c->views_dirty = false;
     return GSX_OK;
@@ -1372,11 +1497,48 @@ int vote_tiebreak_keys(Ctx* c) {
     return GSX_OK;
 }
 
+// Last step of every protocol: the labels (and the device-side range flag) to the host.  D2H lands in pinned memory
+// in kLabelChunks pieces; the worker threads copy piece i into the caller's (pageable) array while piece i+1 is
+// still on the link.  A map that gsx_vote_view_device packed with a label out of range fails the call here.
 static int labels_to_host(Ctx* c, int32_t* labels_out) {
     c->labels_valid = true;
-    if (labels_out && c->n > 0)
-        GSX_HIP(c, hipMemcpyAsync(labels_out, c->labels.p, sizeof(int) * (size_t)c->n, hipMemcpyDeviceToHost, c->stream));
+    const size_t nbytes = labels_out && c->n > 0 ? sizeof(int) * (size_t)c->n : 0;
+    const size_t flag_off = (nbytes + 63) / 64 * 64;
+    const size_t need = flag_off + 64;
+    if (c->h_labels_cap < need) {
+        if (c->h_labels) GSX_HIP(c, hipHostFree(c->h_labels));
+        c->h_labels = nullptr;
+        c->h_labels_cap = 0;
+        GSX_HIP(c, hipHostMalloc(&c->h_labels, need + need / 8, hipHostMallocDefault));
+        c->h_labels_cap = need + need / 8;
+    }
+    char* land = static_cast<char*>(c->h_labels);
+    int* flag = reinterpret_cast<int*>(land + flag_off);
+    GSX_HIP(c, hipMemcpyAsync(flag, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (nbytes) {
+        const int chunks = nbytes >= ((size_t)1 << 20) ? kLabelChunks : 1;
+        const size_t per = ((nbytes + chunks - 1) / chunks + 4095) / 4096 * 4096;
+        for (int k = 0; k < chunks; ++k) {
+            const size_t lo = std::min(nbytes, per * k), hi = std::min(nbytes, per * (k + 1));
+            if (lo < hi)
+                GSX_HIP(c, hipMemcpyAsync(land + lo, c->labels.as<char>() + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
+            if (!c->h_ev[k]) GSX_HIP(c, hipEventCreateWithFlags(&c->h_ev[k], hipEventDisableTiming));
+            GSX_HIP(c, hipEventRecord(c->h_ev[k], c->stream));
+        }
+        Workers* w = host_workers(c);
+        for (int k = 0; k < chunks; ++k) {
+            const size_t lo = std::min(nbytes, per * k), hi = std::min(nbytes, per * (k + 1));
+            GSX_HIP(c, hipEventSynchronize(c->h_ev[k]));
+            if (lo < hi) host_copy(w, reinterpret_cast<char*>(labels_out) + lo, land + lo, hi - lo);
+        }
+    }
     GSX_HIP(c, hipStreamSynchronize(c->stream));
+    if (*flag != kNoBadView) {
+        const int view = *flag;
+        GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0x7f, sizeof(int), c->stream));
+        return fail(c, GSX_E_RANGE, "the segmentation map of view %d (gsx_vote_view_device) holds a label outside [-1, %d]", view,
+                    c->n_classes - 1);
+    }
     return GSX_OK;
 }
 
@@ -1396,6 +1558,48 @@ int vote_labels_from_keys(Ctx* c, int32_t* labels_out) {
 
 FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
 
+// A contiguous range of the Gaussians in upload (Morton) order: the whole scene for a single GPU, one rank's slab in
+// exchange protocol v4.
+struct VoteRange {
+    long long i0, n;
+};
+static FusedParams range_params(Ctx* c, const VoteRange& r, int stride_bytes_per_bin) {
+    FusedParams p = fused_params(c, stride_bytes_per_bin);
+    p.x += r.i0;
+    p.y += r.i0;
+    p.z += r.i0;
+    p.n = r.n;
+    p.perm = nullptr;
+    return p;
+}
+
+// <= 255 staged views: labels straight out of the fused kernel.  perm == nullptr: out[i] = label of Gaussian i0 + i
+// (Morton order); otherwise out[perm[i0 + i]] (the caller's order).
+static int labels_one_batch(Ctx* c, const VoteRange& r, const uint32_t* perm, int* out) {
+    if (r.n <= 0) return GSX_OK;
+    FusedParams p = range_params(c, r, 1);
+    p.perm = perm ? perm + r.i0 : nullptr;
+    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+    // kernel variants: unroll U in {2,4,8} x division mode x batched LDS reads
+    using K = void (*)(FusedParams, const ViewDesc*, int*);
+    const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
+#define GSX_ROW(U_) \
+    {{vote_fused_labels_kernel<U_, kDivExact, false>, vote_fused_labels_kernel<U_, kDivExact, true>},         \
+     {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
+     {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>},           \
+     {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}, \
+     {vote_fused_labels_kernel<U_, kDivFlatCoarse, false>, vote_fused_labels_kernel<U_, kDivFlatCoarse, true>}}
+    static const K table[3][5][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
+#undef GSX_ROW
+    K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
+    int rc = set_lds(c, k, lds);
+    if (rc) return rc;
+    ProfScope ps(c, "vote_fused_labels");
+    hipLaunchKernelGGL(k, dim3(grid_for(r.n)), dim3(kBlock), lds, c->stream, p, p.views, out);
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
 // More than 255 views on one GPU (the reference's own cameras.json holds 311): the views are cut into S balanced
 // batches of <= 255 that play the ranks of exchange protocol v3 on a single device.  Every batch is one launch of the
 // fast u8-histogram walk (vote_fused_counts_kernel) into its own count plane; vote_slab_totals_kernel sums the S
@@ -1403,119 +1607,168 @@ FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
 // tied Gaussians and vote_tie_resolve_kernel takes the earliest batch that voted a candidate = the earliest view,
 // which is the reference's first-inserted rule (dls.py:303).  Replaces the 16-bit count + first-view planes of
 // vote_flush() for this case (1.9 ms per 200 views at C3 sizes against 1.1 ms).
-static int vote_finalize_batched(Ctx* c, int32_t* labels_out) {
-    int rc = sync_views(c);
-    if (rc) return rc;
+// Leaves the range's labels in Morton order at c->keys[0 .. r.n).
+static int labels_batched(Ctx* c, const VoteRange& r) {
     const int nv = (int)c->views.size();
     const int S = (nv + kMaxBatch - 1) / kMaxBatch;
-    const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
+    const long long npad = (r.n + 255) / 256 * 256;
+    const size_t plane = (size_t)c->bins * (size_t)npad;
     GSX_HIP(c, c->bcnt.ensure(plane * S));
-    GSX_HIP(c, c->cand.ensure(sizeof(uint32_t) * kCandWords * (size_t)c->n_pad));
-    GSX_HIP(c, c->bcodes.ensure(sizeof(uint16_t) * (size_t)c->n_pad * S));
-    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)c->n_pad));
+    GSX_HIP(c, c->cand.ensure(sizeof(uint32_t) * kCandWords * (size_t)npad));
+    GSX_HIP(c, c->bcodes.ensure(sizeof(uint16_t) * (size_t)npad * S));
+    if (r.n <= 0) return GSX_OK;
+    const int dm = div_mode(c);
+    auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+             : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
+             : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
+             : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
+                                   : vote_fused_counts_kernel<kUnroll, kDivExact>;
+    FusedParams base = range_params(c, r, 1);
+    const size_t lds = (size_t)kBlock * base.stride_dw * 4;
+    int rc = set_lds(c, k, lds);
+    if (rc) return rc;
+    auto batch = [&](int s, FusedParams& p) {  // views [lo, hi) of batch s, sizes differ by at most one
+        const int lo = (int)((long long)nv * s / S), hi = (int)((long long)nv * (s + 1) / S);
+        p = base;
+        p.views = base.views + lo;
+        p.nviews = hi - lo;
+        if (p.cull) p.cull = base.cull + lo;
+    };
+    for (int s = 0; s < S; ++s) {
+        FusedParams p;
+        batch(s, p);
+        ProfScope ps(c, "vote_fused_counts");
+        hipLaunchKernelGGL(k, dim3(grid_for(r.n)), dim3(kBlock), lds, c->stream, p, p.views, c->bcnt.as<uint8_t>() + plane * s, npad);
+    }
+    GSX_HIP(c, hipGetLastError());
+    {
+        ProfScope ps(c, "vote_slab_totals");
+        hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(npad / 4)), dim3(kBlock), 0, c->stream, c->bcnt.as<uint8_t>(), S,
+                           c->bins, npad, c->keys.as<int>(), c->cand.as<uint32_t>());
+    }
+    for (int s = 0; s < S; ++s) {
+        FusedParams p;
+        batch(s, p);
+        ProfScope ps(c, "vote_tie");
+        hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(r.n)), dim3(kBlock), 0, c->stream, p, p.views, c->cand.as<uint32_t>(), npad,
+                           c->bcodes.as<uint16_t>() + (size_t)npad * s);
+    }
+    {
+        ProfScope ps(c, "vote_tie_resolve");
+        hipLaunchKernelGGL(vote_tie_resolve_kernel, dim3(grid_for(npad)), dim3(kBlock), 0, c->stream, c->bcodes.as<uint16_t>(), S, npad,
+                           c->keys.as<int>());
+    }
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+// labels of a range of Gaussians over ALL staged views, whatever their number.  to_sorted: leave them in Morton order
+// at c->keys[0 .. r.n) (protocol v4); otherwise write c->labels in the caller's order (needs r = the whole scene).
+static int labels_for_range(Ctx* c, const VoteRange& r, bool to_sorted) {
+    int rc = sync_views(c);
+    if (rc) return rc;
+    GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
     GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
-    if (c->n > 0) {
-        const int dm = div_mode(c);
-        auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
-                 : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
-                 : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
-                 : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
-                                       : vote_fused_counts_kernel<kUnroll, kDivExact>;
-        FusedParams base = fused_params(c, 1);
-        const size_t lds = (size_t)kBlock * base.stride_dw * 4;
-        if ((rc = set_lds(c, k, lds))) return rc;
-        auto batch = [&](int s, FusedParams& p) {  // views [lo, hi) of batch s, sizes differ by at most one
-            const int lo = (int)((long long)nv * s / S), hi = (int)((long long)nv * (s + 1) / S);
-            p = base;
-            p.views = base.views + lo;
-            p.nviews = hi - lo;
-            if (p.cull) p.cull = base.cull + lo;
-        };
-        for (int s = 0; s < S; ++s) {
-            FusedParams p;
-            batch(s, p);
-            ProfScope ps(c, "vote_fused_counts");
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->bcnt.as<uint8_t>() + plane * s,
-                               (long long)c->n_pad);
-        }
-        GSX_HIP(c, hipGetLastError());
-        {
-            ProfScope ps(c, "vote_slab_totals");
-            hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(c->n_pad / 4)), dim3(kBlock), 0, c->stream,
-                               c->bcnt.as<uint8_t>(), S, c->bins, (long long)c->n_pad, c->keys.as<int>(), c->cand.as<uint32_t>());
-        }
-        for (int s = 0; s < S; ++s) {
-            FusedParams p;
-            batch(s, p);
-            ProfScope ps(c, "vote_tie");
-            hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, p, p.views, c->cand.as<uint32_t>(),
-                               (long long)c->n_pad, c->bcodes.as<uint16_t>() + (size_t)c->n_pad * s);
-        }
-        {
-            ProfScope ps(c, "vote_tie_resolve");
-            hipLaunchKernelGGL(vote_tie_resolve_kernel, dim3(grid_for(c->n_pad)), dim3(kBlock), 0, c->stream, c->bcodes.as<uint16_t>(), S,
-                               (long long)c->n_pad, c->keys.as<int>());
-        }
-        {
-            ProfScope ps(c, "vote_labels");
-            hipLaunchKernelGGL(unpermute_labels_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, c->keys.as<int>(),
-                               (long long)c->n, c->sorted ? c->perm.as<uint32_t>() : nullptr, c->labels.as<int>());
-        }
+    const uint32_t* perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
+    if ((int)c->views.size() <= kMaxBatch)
+        return labels_one_batch(c, r, to_sorted ? nullptr : perm, to_sorted ? c->keys.as<int>() : c->labels.as<int>());
+    if ((rc = labels_batched(c, r))) return rc;
+    if (!to_sorted && r.n > 0) {
+        ProfScope ps(c, "vote_labels");
+        hipLaunchKernelGGL(unpermute_labels_kernel, dim3(grid_for(r.n)), dim3(kBlock), 0, c->stream, c->keys.as<int>(), r.n, perm,
+                           c->labels.as<int>());
         GSX_HIP(c, hipGetLastError());
     }
-    return labels_to_host(c, labels_out);
+    return GSX_OK;
 }
 
 int vote_finalize(Ctx* c, int32_t* labels_out) {
     if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_finalize before vote_begin");
     GSX_HIP(c, hipSetDevice(c->device));
     const int nv = (int)c->views.size();
-    if (c->n_flushed == 0 && nv > kMaxBatch && !c->local_codes && c->opt_batched_counts) return vote_finalize_batched(c, labels_out);
-    if (c->n_flushed == 0 && nv <= kMaxBatch) {
-        // single batch, nothing in the planes: labels come straight out of the fused kernel
-        int rc = sync_views(c);
+    const bool batched_ok = !c->local_codes && c->opt_batched_counts;
+    if (c->n_flushed == 0 && (nv <= kMaxBatch || batched_ok)) {
+        // nothing in the planes yet: labels come straight out of the fused kernel(s)
+        int rc = labels_for_range(c, VoteRange{0, c->n}, false);
         if (rc) return rc;
-        GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
-        if (c->n > 0) {
-            FusedParams p{};
-            p.x = c->x.as<float>();
-            p.y = c->y.as<float>();
-            p.z = c->z.as<float>();
-            p.n = c->n;
-            p.views = c->d_views.as<ViewDesc>();
-            p.nviews = nv;
-            p.pool = c->segpool.as<uint8_t>();
-            p.bins = c->bins;
-            p.xcd_swizzle = c->opt_xcd_swizzle;
-            p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
-            p.stride_dw = odd_dwords(c->bins);
-            p.cull = c->opt_wave_cull ? c->d_cull.as<double>() : nullptr;
-            p.cull_pitch = c->cull_pitch;
-            p.cull_tally = c->d_cull_tally.as<unsigned long long>();
-                    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-            // kernel variants: unroll U in {2,4,8} x division mode x batched LDS reads
-            using K = void (*)(FusedParams, const ViewDesc*, int*);
-            const int ui = c->opt_vote_unroll == 2 ? 0 : c->opt_vote_unroll == 4 ? 1 : 2;
-#define GSX_ROW(U_) \
-    {{vote_fused_labels_kernel<U_, kDivExact, false>, vote_fused_labels_kernel<U_, kDivExact, true>},         \
-     {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
-     {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>},           \
-     {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}, \
-     {vote_fused_labels_kernel<U_, kDivFlatCoarse, false>, vote_fused_labels_kernel<U_, kDivFlatCoarse, true>}}
-            static const K table[3][5][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
-#undef GSX_ROW
-            K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
-            if ((rc = set_lds(c, k, lds))) return rc;
-            ProfScope ps(c, "vote_fused_labels");
-            hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->labels.as<int>());
-            GSX_HIP(c, hipGetLastError());
-        }
         return labels_to_host(c, labels_out);
     }
     int rc = vote_flush(c);
     if (rc) return rc;
     if ((rc = vote_tiebreak_keys(c))) return rc;
     return vote_labels_from_keys(c, labels_out);
+}
+
+// ---- exchange v4 host side: views sharded for the hand-over, Gaussians sharded for the vote ------------------------
+// The packed maps of 200 1080p views are 0.44 GB; the dense vote histogram of 3 M Gaussians is 0.45 GB PER RANK.  So
+// the maps travel (one all-gather), not the votes: afterwards every rank holds every view, votes its own slab of
+// the Gaussians with the single-GPU kernel, and only 4 bytes per Gaussian (the labels) are gathered.  No histogram,
+// no tie-break exchange: a slab sees all views in order, the tie rule is the single-GPU one.
+int vote_export(Ctx* c, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_export before vote_begin");
+    if (c->pool_base) return fail(c, GSX_E_STATE, "vote_export after vote_import");
+    GSX_HIP(c, hipSetDevice(c->device));
+    if (reserve_bytes < 0) return fail(c, GSX_E_INVALID, "vote_export: negative size");
+    const size_t used = (c->seg_used + 255) / 256 * 256;
+    int rc = pool_reserve(c, std::max<size_t>(std::max<size_t>((size_t)reserve_bytes, used), 256));
+    if (rc) return rc;
+    c->views_dirty = true;  // the pool may have moved
+    static_assert(sizeof(ViewDesc) == GSX_VIEW_BLOB_BYTES, "view blob size is part of the ABI");
+    if (blobs_out && !c->views.empty()) std::memcpy(blobs_out, c->views.data(), sizeof(ViewDesc) * c->views.size());
+    if (pool_dev) *pool_dev = c->segpool.p;
+    if (pool_bytes) *pool_bytes = (int64_t)used;
+    return GSX_OK;
+}
+
+int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
+                const void* pool_all_dev, int64_t pool_all_bytes) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_import before vote_begin");
+    if (n_parts < 1 || !part_views || !part_offsets || !pool_all_dev || pool_all_bytes < 0)
+        return fail(c, GSX_E_INVALID, "vote_import: bad arguments");
+    long long total = 0;
+    for (int r = 0; r < n_parts; ++r) {
+        if (part_views[r] < 0 || part_offsets[r] < 0) return fail(c, GSX_E_INVALID, "vote_import: negative count or offset");
+        total += part_views[r];
+    }
+    if (total > 65535) return fail(c, GSX_E_RANGE, "vote_import: %lld views exceed 65535", total);
+    if (total > 0 && !blobs) return fail(c, GSX_E_INVALID, "vote_import: blobs is NULL");
+    std::vector<ViewDesc> all((size_t)total);
+    if (total) std::memcpy(all.data(), blobs, sizeof(ViewDesc) * (size_t)total);
+    size_t k = 0;
+    for (int r = 0; r < n_parts; ++r)
+        for (int v = 0; v < part_views[r]; ++v, ++k) {
+            ViewDesc& d = all[k];
+            // the blob comes from another process: check what the kernels rely on before any address is formed from it
+            const MapLayout L = map_layout(d.seg_w, d.seg_h, d.seg_row_bytes != 0, d.coarse_row_bytes != 0);
+            const bool ok = d.seg_w >= 1 && d.seg_h >= 1 && d.seg_w <= 65535 && d.seg_h <= 65535 && d.seg_off >= 0 &&
+                            d.seg_row_bytes == L.strip_bytes && d.coarse_row_bytes == L.cstrip_bytes &&
+                            (!d.coarse_row_bytes || d.coarse_delta == (unsigned)L.coarse_off) &&
+                            (unsigned long long)d.seg_off + (unsigned long long)part_offsets[r] + L.map_bytes <= (unsigned long long)pool_all_bytes;
+            if (!ok) return fail(c, GSX_E_INVALID, "vote_import: descriptor %zu (part %d) is inconsistent with the gathered pool", k, r);
+            d.seg_off += part_offsets[r];
+        }
+    c->views.swap(all);
+    c->views_dirty = true;
+    c->pool_base = pool_all_dev;
+    c->first_view = 0;
+    c->n_flushed = 0;
+    c->labels_valid = false;
+    return GSX_OK;
+}
+
+int vote_slab_labels(Ctx* c, int slab, int slabs, int64_t* slab_size) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_slab_labels before vote_begin");
+    if (slabs < 1 || slab < 0 || slab >= slabs) return fail(c, GSX_E_INVALID, "vote_slab_labels: slab %d of %d", slab, slabs);
+    GSX_HIP(c, hipSetDevice(c->device));
+    long long sn = ((c->n + slabs - 1) / slabs + 255) / 256 * 256;
+    if (sn == 0) sn = 256;
+    if (slab_size) *slab_size = sn;
+    const long long i0 = std::min<long long>(c->n, sn * slab);
+    const long long cnt = std::min<long long>(c->n - i0, sn);
+    if ((long long)sn > c->n_pad) {  // tiny scenes: the key buffer must hold one whole slab for the all-gather
+        GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)sn));
+    }
+    return labels_for_range(c, VoteRange{i0, cnt}, true);
 }
 
 // ---- exchange v3 host side ------------------------------------------------------------------------------------
@@ -1577,8 +1830,7 @@ int vote_slab_totals(Ctx* c, const void* recv_cnt) {
     hipLaunchKernelGGL(vote_slab_totals_kernel, dim3(grid_for(c->sn / 4)), dim3(kBlock), 0, c->stream, (const uint8_t*)recv_cnt,
                        c->slabs, c->bins, (long long)c->sn, c->keys.as<int>(), c->cand.as<uint32_t>());
     GSX_HIP(c, hipGetLastError());
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    return GSX_OK;
+    return GSX_OK;  // ordered by the ctx stream; nothing waits on the host
 }
 
 int vote_tie_codes(Ctx* c, const void* cand_all) {
@@ -1597,8 +1849,7 @@ int vote_tie_codes(Ctx* c, const void* cand_all) {
                            (const uint32_t*)cand_all, (long long)c->sn, c->codes.as<uint16_t>());
         GSX_HIP(c, hipGetLastError());
     }
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    return GSX_OK;
+    return GSX_OK;  // ordered by the ctx stream; nothing waits on the host
 }
 
 int vote_tie_resolve(Ctx* c, const void* recv_codes) {
@@ -1609,8 +1860,7 @@ int vote_tie_resolve(Ctx* c, const void* recv_codes) {
     hipLaunchKernelGGL(vote_tie_resolve_kernel, dim3(grid_for(c->sn)), dim3(kBlock), 0, c->stream, (const uint16_t*)recv_codes,
                        c->slabs, (long long)c->sn, c->keys.as<int>());
     GSX_HIP(c, hipGetLastError());
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    return GSX_OK;
+    return GSX_OK;  // ordered by the ctx stream; nothing waits on the host
 }
 
 int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv) {
@@ -1622,8 +1872,7 @@ int vote_slab_reduce(Ctx* c, const void* recv_cnt, const void* recv_fv) {
     hipLaunchKernelGGL(vote_slab_reduce_kernel, dim3(grid_for(c->sn)), dim3(kBlock), 0, c->stream, (const uint8_t*)recv_cnt,
                        (const uint8_t*)recv_fv, c->slabs, c->bins, (long long)c->sn, c->keys.as<int>());
     GSX_HIP(c, hipGetLastError());
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    return GSX_OK;
+    return GSX_OK;  // ordered by the ctx stream; nothing waits on the host
 }
 
 int vote_labels_from_sorted(Ctx* c, const void* sorted_labels_dev, int32_t* labels_out) {

@@ -12,6 +12,8 @@ Protocol (exact, including the reference's first-inserted-label tie rule, dls.py
 Ranks must own contiguous, rank-ordered view ranges [first_view, first_view + k) so that the
 global view index orders first votes exactly as the single-process loop (dls.py:255) does.
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -29,28 +31,49 @@ def device_words_tensor(ptr, n_words, device):
     return torch.as_tensor(_DeviceWords(ptr, n_words), device=torch.device("cuda", device))
 
 
-class GpuVoteShard:
-    """One rank's vote state on its MI355X (the product path)."""
+class _DeviceBytes:
+    def __init__(self, ptr, n_bytes):
+        self.__cuda_array_interface__ = {"shape": (int(n_bytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def device_bytes_tensor(ptr, n_bytes, device):
+    return torch.as_tensor(_DeviceBytes(ptr, n_bytes), device=torch.device("cuda", device))
+
+
+class _GpuShard:
+    """Common part of the GPU shards: every collective is issued with the ctx's own HIP stream as torch's current
+    stream, so libgsx kernels, RCCL collectives and the copies in between are ordered by the stream (RCCL's internal
+    stream joins it through events) and the host never waits between the stages of a protocol."""
 
     def __init__(self, ctx):
         self.ctx = ctx
+        self._ext = None
+
+    def stream(self):
+        if self._ext is None:
+            self._ext = torch.cuda.ExternalStream(self.ctx.stream, device=torch.device("cuda", self.ctx.device))
+        return torch.cuda.stream(self._ext)
+
+
+def _stream_of(shard):
+    return shard.stream() if hasattr(shard, "stream") else contextlib.nullcontext()
+
+
+class GpuVoteShard(_GpuShard):
+    """One rank's vote state on its MI355X (the product path)."""
 
     def counts_tensor(self):
         self.ctx.vote_flush()
         ptr, n = self.ctx.counts_device()
-        self.ctx.synchronize()
         return device_words_tensor(ptr, n, self.ctx.device)
 
     def compute_keys(self):
-        torch.cuda.synchronize(self.ctx.device)      # the reduced counts must have landed
         self.ctx.vote_tiebreak_keys()
         ptr, n = self.ctx.keys_device()
-        self.ctx.synchronize()
         return device_words_tensor(ptr, n, self.ctx.device)
 
-    def labels(self, to_host=True):
-        torch.cuda.synchronize(self.ctx.device)
-        return self.ctx.vote_labels_from_keys(to_host)
+    def labels(self, to_host=True, out=None):
+        return self.ctx.vote_labels_from_keys(to_host, out=out)
 
 
 class HostVoteShard:
@@ -66,20 +89,28 @@ class HostVoteShard:
         self.shard.compute_keys()
         return torch.from_numpy(self.shard.keys)
 
-    def labels(self, to_host=True):
-        return self.shard.labels_from_keys()
+    def labels(self, to_host=True, out=None):
+        return _into(out, self.shard.labels_from_keys())
 
 
-def exchange_labels(shard, group=None, to_host=True):
+def _into(out, labels):
+    if out is None:
+        return labels
+    out[...] = labels
+    return out
+
+
+def exchange_labels(shard, group=None, to_host=True, out=None):
     """Steps 2-5 above.  `shard` is a GpuVoteShard (RCCL) or HostVoteShard (gloo)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    counts = shard.counts_tensor()
-    if world > 1:
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
-    keys = shard.compute_keys()
-    if world > 1:
-        dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
-    return shard.labels(to_host)
+    with _stream_of(shard):
+        counts = shard.counts_tensor()
+        if world > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        keys = shard.compute_keys()
+        if world > 1:
+            dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
+        return shard.labels(to_host, out=out)
 
 
 # ---- protocol v2: all-to-all (reduce-scatter by hand) -> local arg-max -> all-gather of labels -------------
@@ -90,30 +121,24 @@ def exchange_labels(shard, group=None, to_host=True):
 #   4. all_gather of the sn int32 labels per rank; back to the caller's order
 # Moves 2*(world-1)/world * bins*n bytes per rank instead of the all-reduce's ~2*(world-1)/world * 2*bins*n
 # (16-bit counters), and the wide histogram crosses xGMI once.
-class GpuSlabShard:
+class GpuSlabShard(_GpuShard):
     """Rank-local state of protocol v2 on the GPU.  The ctx must have been configured with
     configure_a2a(ctx, world) BEFORE upload/vote_begin."""
-
-    def __init__(self, ctx):
-        self.ctx = ctx
 
     def planes(self):
         self.ctx.vote_flush()
         cp, words = self.ctx.counts_device()
         fp, _ = self.ctx.first_device()
-        self.ctx.synchronize()
         dev = self.ctx.device
         return device_words_tensor(cp, words, dev), device_words_tensor(fp, words, dev)
 
     def reduce(self, recv_cnt, recv_fv):
-        torch.cuda.synchronize(self.ctx.device)
         self.ctx.vote_slab_reduce(recv_cnt.data_ptr(), recv_fv.data_ptr())
         kp, _ = self.ctx.keys_device()
         return device_words_tensor(kp, self.ctx.slab_size(), self.ctx.device)
 
-    def finish(self, all_labels, to_host=True):
-        torch.cuda.synchronize(self.ctx.device)
-        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host)
+    def finish(self, all_labels, to_host=True, out=None):
+        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host, out=out)
 
 
 class HostSlabShard:
@@ -128,8 +153,8 @@ class HostSlabShard:
     def reduce(self, recv_cnt, recv_fv):
         return torch.from_numpy(self.shard.reduce(recv_cnt.numpy().view(np.uint8), recv_fv.numpy().view(np.uint8)))
 
-    def finish(self, all_labels, to_host=True):
-        return self.shard.finish(all_labels.numpy())
+    def finish(self, all_labels, to_host=True, out=None):
+        return _into(out, self.shard.finish(all_labels.numpy()))
 
 
 def configure_a2a(ctx, world):
@@ -164,23 +189,24 @@ def _all_gather_into(full, part, group):
         dist.all_gather_into_tensor(full, part.contiguous(), group=group)
 
 
-def exchange_labels_a2a(shard, group=None, to_host=True):
+def exchange_labels_a2a(shard, group=None, to_host=True, out=None):
     """Steps 2-4 of protocol v2.  `shard` is a GpuSlabShard (RCCL) or HostSlabShard (gloo)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
-    cnt, fv = shard.planes()
-    if world > 1:
-        rc, rf = torch.empty_like(cnt), torch.empty_like(fv)
-        _all_to_all(rc, cnt, group)
-        _all_to_all(rf, fv, group)
-    else:
-        rc, rf = cnt, fv
-    slab = shard.reduce(rc, rf)
-    if world > 1:
-        full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
-        _all_gather_into(full, slab, group)
-    else:
-        full = slab
-    return shard.finish(full, to_host)
+    with _stream_of(shard):
+        cnt, fv = shard.planes()
+        if world > 1:
+            rc, rf = torch.empty_like(cnt), torch.empty_like(fv)
+            _all_to_all(rc, cnt, group)
+            _all_to_all(rf, fv, group)
+        else:
+            rc, rf = cnt, fv
+        slab = shard.reduce(rc, rf)
+        if world > 1:
+            full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
+            _all_gather_into(full, slab, group)
+        else:
+            full = slab
+        return shard.finish(full, to_host, out=out)
 
 
 # ---- protocol v3: counts-only all-to-all + sparse tie pass ------------------------------------------------------
@@ -191,38 +217,30 @@ def exchange_labels_a2a(shard, group=None, to_host=True):
 #   4. all_to_all(codes); slab owner: lowest rank with a code = globally earliest view -> label
 #   5. all_gather(labels)
 # Half of v2's bytes on the fabric, and the rank-local kernel is the 16-waves/CU one.
-class GpuSparseShard:
-    def __init__(self, ctx):
-        self.ctx = ctx
-
+class GpuSparseShard(_GpuShard):
     def _t(self, ptr_words):
         ptr, words = ptr_words
         return device_words_tensor(ptr, words, self.ctx.device)
 
     def counts(self):
         self.ctx.vote_flush_counts()
-        self.ctx.synchronize()
         return self._t(self.ctx.counts_device())
 
     def totals(self, recv_cnt):
-        torch.cuda.synchronize(self.ctx.device)
         self.ctx.vote_slab_totals(recv_cnt.data_ptr())
         return self._t(self.ctx.cand_device())
 
     def tie_codes(self, cand_all):
-        torch.cuda.synchronize(self.ctx.device)
         self.ctx.vote_tie_codes(cand_all.data_ptr())
         return self._t(self.ctx.codes_device())
 
     def resolve(self, recv_codes):
-        torch.cuda.synchronize(self.ctx.device)
         self.ctx.vote_tie_resolve(recv_codes.data_ptr())
         kp, _ = self.ctx.keys_device()
         return device_words_tensor(kp, self.ctx.slab_size(), self.ctx.device)
 
-    def finish(self, all_labels, to_host=True):
-        torch.cuda.synchronize(self.ctx.device)
-        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host)
+    def finish(self, all_labels, to_host=True, out=None):
+        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host, out=out)
 
 
 class HostSparseShard:
@@ -243,12 +261,17 @@ class HostSparseShard:
     def resolve(self, recv_codes):
         return torch.from_numpy(self.shard.resolve(recv_codes.numpy().view(np.uint16)))
 
-    def finish(self, all_labels, to_host=True):
-        return self.shard.finish(all_labels.numpy())
+    def finish(self, all_labels, to_host=True, out=None):
+        return _into(out, self.shard.finish(all_labels.numpy()))
 
 
-def exchange_labels_sparse(shard, group=None, to_host=True):
+def exchange_labels_sparse(shard, group=None, to_host=True, out=None):
     """Protocol v3.  `shard` is a GpuSparseShard (RCCL) or HostSparseShard (gloo)."""
+    with _stream_of(shard):
+        return _exchange_labels_sparse(shard, group, to_host, out)
+
+
+def _exchange_labels_sparse(shard, group, to_host, out):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     cnt = shard.counts()
     if world > 1:
@@ -274,7 +297,131 @@ def exchange_labels_sparse(shard, group=None, to_host=True):
         _all_gather_into(full, slab, group)
     else:
         full = slab
-    return shard.finish(full, to_host)
+    return shard.finish(full, to_host, out=out)
+
+
+# ---- protocol v4: all-gather of the packed maps -> every rank votes its slab of the Gaussians -> all-gather of labels
+#   0. every rank has staged its contiguous, rank-ordered block of views (packed u8 maps in its pool)
+#   1. all_gather of a small header per rank: view count, pool bytes, the view blobs (camera + map geometry)
+#   2. all_gather of the pools, padded to the largest (`chunk` bytes per rank): 0.44 GB in total for 200 1080p views,
+#      against a 0.45 GB histogram PER RANK in v1-v3
+#   3. import: every rank now holds all views; it votes Gaussians [rank*S, (rank+1)*S) of the Morton order with the
+#      single-GPU fused kernel (all views in order -> the reference's tie rule needs no exchange)
+#   4. all_gather of the S int32 labels per rank; back to the caller's order
+_HDR = 16  # bytes: int64 views, int64 pool bytes
+
+
+class GpuGatherShard(_GpuShard):
+    def __init__(self, ctx):
+        super().__init__(ctx)
+        self._pool_all = None
+        self._labels_all = None
+
+    def header(self, cap_views):
+        """uint8 tensor [_HDR + 256 * cap_views] on the device: this rank's view count, pool bytes and view blobs."""
+        _, used, blobs = self.ctx.vote_export(0)
+        h = np.zeros(_HDR + 256 * cap_views, np.uint8)
+        h[:_HDR].view(np.int64)[:] = (len(blobs), used)
+        h[_HDR:_HDR + blobs.size] = blobs.reshape(-1)
+        return torch.from_numpy(h).to(torch.device("cuda", self.ctx.device), non_blocking=False)
+
+    def pool(self, chunk):
+        ptr, _, _ = self.ctx.vote_export(chunk, blobs=False)
+        return device_bytes_tensor(ptr, chunk, self.ctx.device)
+
+    def pool_all(self, nbytes):
+        if self._pool_all is None or self._pool_all.numel() < nbytes:
+            self._pool_all = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", self.ctx.device))
+        return self._pool_all[:nbytes]
+
+    def import_all(self, part_views, part_offsets, blobs, pool_all):
+        self.ctx.vote_import(part_views, part_offsets, blobs, pool_all.data_ptr(), pool_all.numel())
+
+    def slab_labels(self, rank, world):
+        sn = self.ctx.vote_slab_labels(rank, world)
+        kp, _ = self.ctx.keys_device()
+        return device_words_tensor(kp, sn, self.ctx.device)
+
+    def labels_all(self, n):
+        if self._labels_all is None or self._labels_all.numel() < n:
+            self._labels_all = torch.empty(n, dtype=torch.int32, device=torch.device("cuda", self.ctx.device))
+        return self._labels_all[:n]
+
+    def finish(self, all_labels, to_host=True, out=None):
+        return self.ctx.vote_labels_from_sorted(all_labels.data_ptr(), to_host, out=out)
+
+
+class HostGatherShard:
+    """Adapter for a numpy-backed v4 shard (tests, gloo)."""
+
+    def __init__(self, shard):
+        self.shard = shard
+
+    def header(self, cap_views):
+        blobs, used = self.shard.export()
+        h = np.zeros(_HDR + 256 * cap_views, np.uint8)
+        h[:_HDR].view(np.int64)[:] = (len(blobs), used)
+        h[_HDR:_HDR + blobs.size] = blobs.reshape(-1)
+        return torch.from_numpy(h)
+
+    def pool(self, chunk):
+        return torch.from_numpy(self.shard.pool(chunk))
+
+    def pool_all(self, nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8)
+
+    def import_all(self, part_views, part_offsets, blobs, pool_all):
+        self.shard.import_all(part_views, part_offsets, blobs, pool_all.numpy())
+
+    def slab_labels(self, rank, world):
+        return torch.from_numpy(self.shard.slab_labels(rank, world))
+
+    def labels_all(self, n):
+        return torch.empty(n, dtype=torch.int32)
+
+    def finish(self, all_labels, to_host=True, out=None):
+        return _into(out, self.shard.finish(all_labels.numpy()))
+
+
+def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=None):
+    """Protocol v4.  `shard` is a GpuGatherShard (RCCL) or HostGatherShard (gloo).  cap_views: an upper bound on the
+    views of any one rank that all ranks agree on (default: 1024); sizes the header exchange."""
+    on = dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    cap = int(cap_views) if cap_views else 1024
+    # 1. headers.  Issued on torch's own stream, NOT the ctx stream: it does not have to wait for the maps' DMA.
+    mine = shard.header(cap)
+    if world > 1:
+        heads = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+        _all_gather_into(heads, mine, group)
+    else:
+        heads = mine
+    heads = heads.cpu().numpy().reshape(world, -1)
+    counts = heads[:, :_HDR].copy().view(np.int64).reshape(world, 2)
+    part_views = counts[:, 0].astype(np.int32)
+    if int(part_views.max()) > cap:
+        raise ValueError(f"exchange_labels_gather: a rank staged {int(part_views.max())} views, more than cap_views={cap}")
+    chunk = max(256, int(counts[:, 1].max()))
+    blobs = np.concatenate([heads[r, _HDR:_HDR + 256 * part_views[r]] for r in range(world)])
+    with _stream_of(shard):
+        # 2. the maps
+        pool = shard.pool(chunk)
+        if world > 1:
+            pool_all = shard.pool_all(world * chunk)
+            _all_gather_into(pool_all, pool, group)
+        else:
+            pool_all = pool
+        # 3. my slab of the Gaussians over all views
+        shard.import_all(part_views, np.arange(world, dtype=np.int64) * chunk, blobs, pool_all)
+        slab = shard.slab_labels(rank, world)
+        # 4. the labels
+        if world > 1:
+            full = shard.labels_all(slab.numel() * world)
+            _all_gather_into(full, slab, group)
+        else:
+            full = slab
+        return shard.finish(full, to_host, out=out)
 
 
 def view_range(n_views_total, rank, world):

@@ -32,6 +32,7 @@ class Context:
         check(self._lib.gsx_create(int(device), C.byref(h)))
         self.h = h
         self.device = int(device)
+        self._keep_alive = []   # device maps handed to vote_view until the ctx stream has consumed them
 
     def close(self):
         if getattr(self, "h", None):
@@ -93,20 +94,31 @@ class Context:
 
     # -- vote --------------------------------------------------------------------------------------
     def vote_begin(self, n_classes, first_view=0, total_views=255):
+        self._keep_alive.clear()
         check(self._lib.gsx_vote_begin(self.h, n_classes, first_view, total_views), self.h)
 
-    def vote_view(self, camera, seg_map, image_size=None):
-        """seg_map: 2-D int array (values -1..n_classes-1) on the host, or a torch tensor on this GPU.
-        image_size: (width, height) of the input image; defaults to the map's own size."""
+    _TORCH_DT = {"torch.int32": _lib.GSX_SEG_I32, "torch.int64": _lib.GSX_SEG_I64, "torch.uint8": _lib.GSX_SEG_U8_LABELS}
+
+    def vote_view(self, camera, seg_map, image_size=None, packed_u8=False):
+        """seg_map: 2-D int array of labels (-1..n_classes-1; any integer dtype, as the reference accepts) on the host,
+        or a torch tensor on this GPU.  image_size: (width, height) of the input image; defaults to the map's own size.
+        packed_u8: a uint8 map already holds label+1 (0 = label -1), the library's own compact form.
+        Host maps are range-checked here (ValueError); device maps when the labels are fetched."""
         cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
         if hasattr(seg_map, "data_ptr"):  # torch tensor on the device
             t = seg_map.contiguous()
             h, w = t.shape
-            dt = {"torch.int32": _lib.GSX_SEG_I32, "torch.int64": _lib.GSX_SEG_I64, "torch.uint8": _lib.GSX_SEG_U8}[str(t.dtype)]
-            iw, ih = image_size if image_size is not None else (w, h)
             if not t.is_cuda:
                 raise ValueError("tensor seg maps must live on the GPU; pass numpy arrays for host maps")
+            dt = self._TORCH_DT.get(str(t.dtype))
+            if dt is None:
+                import torch
+                t, dt = t.to(torch.int32), _lib.GSX_SEG_I32
+            if packed_u8 and dt == _lib.GSX_SEG_U8_LABELS:
+                dt = _lib.GSX_SEG_U8
+            iw, ih = image_size if image_size is not None else (w, h)
             check(self._lib.gsx_vote_view_device(self.h, C.byref(cam), t.data_ptr(), dt, w, h, int(iw), int(ih)), self.h)
+            self._keep_alive.append(t)   # the pack kernel runs asynchronously on the ctx stream
             return
         seg = np.asarray(seg_map)
         if seg.ndim != 2:
@@ -114,7 +126,7 @@ class Context:
         if seg.dtype == np.int64:
             dt = _lib.GSX_SEG_I64
         elif seg.dtype == np.uint8:
-            dt = _lib.GSX_SEG_U8
+            dt = _lib.GSX_SEG_U8 if packed_u8 else _lib.GSX_SEG_U8_LABELS
         else:
             seg = seg.astype(np.int32, copy=False)
             dt = _lib.GSX_SEG_I32
@@ -123,13 +135,38 @@ class Context:
         iw, ih = image_size if image_size is not None else (w, h)
         check(self._lib.gsx_vote_view(self.h, C.byref(cam), seg.ctypes.data, dt, w, h, int(iw), int(ih)), self.h)
 
+    def vote_views_device(self, cameras, seg_tensors, image_size=None, packed_u8=False):
+        """Several device-resident maps of one shape and dtype in one call (gsx_vote_views_device: 16 maps per kernel
+        launch).  seg_tensors: list of 2-D torch tensors on this GPU, or one 3-D tensor (views, H, W)."""
+        ts = [t.contiguous() for t in seg_tensors]
+        if not ts:
+            return
+        h, w = ts[0].shape
+        dt = self._TORCH_DT[str(ts[0].dtype)]
+        if packed_u8 and dt == _lib.GSX_SEG_U8_LABELS:
+            dt = _lib.GSX_SEG_U8
+        if any(t.shape != ts[0].shape or t.dtype != ts[0].dtype or not t.is_cuda for t in ts):
+            raise ValueError("vote_views_device: all maps must share shape and dtype and live on the GPU")
+        cams = (Camera * len(ts))(*[c if isinstance(c, Camera) else Camera.from_dict(c) for c in cameras])
+        ptrs = (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+        iw, ih = image_size if image_size is not None else (w, h)
+        check(self._lib.gsx_vote_views_device(self.h, len(ts), cams, ptrs, dt, w, h, int(iw), int(ih)), self.h)
+        self._keep_alive.extend(ts)
+
     def vote_rewind(self):
         check(self._lib.gsx_vote_rewind(self.h), self.h)
 
-    def vote_finalize(self, to_host=True):
-        out = np.empty(self.n, np.int32) if to_host else None
-        check(self._lib.gsx_vote_finalize(self.h, out.ctypes.data if to_host else None), self.h)
-        return out
+    def vote_finalize(self, to_host=True, out=None):
+        """out: optional preallocated int32 array of N labels (saves the page faults of a fresh 12 MB array)."""
+        if to_host and out is None:
+            out = np.empty(self.n, np.int32)
+        if to_host and (out.dtype != np.int32 or out.shape != (self.n,) or not out.flags.c_contiguous):
+            raise ValueError("out must be a contiguous int32 array of N labels")
+        try:
+            check(self._lib.gsx_vote_finalize(self.h, out.ctypes.data if to_host else None), self.h)
+        finally:
+            self._keep_alive.clear()     # the stream has been synchronised
+        return out if to_host else None
 
     def vote_flush(self):
         check(self._lib.gsx_vote_flush(self.h), self.h)
@@ -137,10 +174,14 @@ class Context:
     def vote_tiebreak_keys(self):
         check(self._lib.gsx_vote_tiebreak_keys(self.h), self.h)
 
-    def vote_labels_from_keys(self, to_host=True):
-        out = np.empty(self.n, np.int32) if to_host else None
-        check(self._lib.gsx_vote_labels_from_keys(self.h, out.ctypes.data if to_host else None), self.h)
-        return out
+    def vote_labels_from_keys(self, to_host=True, out=None):
+        if to_host and out is None:
+            out = np.empty(self.n, np.int32)
+        try:
+            check(self._lib.gsx_vote_labels_from_keys(self.h, out.ctypes.data if to_host else None), self.h)
+        finally:
+            self._keep_alive.clear()
+        return out if to_host else None
 
     def counts_device(self):
         n = C.c_int64()
@@ -185,11 +226,15 @@ class Context:
     def vote_tie_resolve(self, recv_codes_ptr):
         check(self._lib.gsx_vote_tie_resolve(self.h, C.c_void_p(recv_codes_ptr)), self.h)
 
-    def vote_labels_from_sorted(self, sorted_ptr, to_host=True):
-        out = np.empty(self.n, np.int32) if to_host else None
-        check(self._lib.gsx_vote_labels_from_sorted(self.h, C.c_void_p(sorted_ptr), out.ctypes.data if to_host else None),
-              self.h)
-        return out
+    def vote_labels_from_sorted(self, sorted_ptr, to_host=True, out=None):
+        if to_host and out is None:
+            out = np.empty(self.n, np.int32)
+        try:
+            check(self._lib.gsx_vote_labels_from_sorted(self.h, C.c_void_p(sorted_ptr), out.ctypes.data if to_host else None),
+                  self.h)
+        finally:
+            self._keep_alive.clear()
+        return out if to_host else None
 
     def kmeans(self, points, colors, k, init_index, max_iter=100, tol=1e-4):
         """k_means_with_color (3D_clustering/k_means.py:107-151) with injected initial rows.
@@ -207,6 +252,35 @@ class Context:
         check(self._lib.gsx_kmeans(self.h, len(pts), pts.ctypes.data, col.ctypes.data, int(k), init.ctypes.data, int(max_iter),
                                    float(tol), labels.ctypes.data, cent.ctypes.data, C.byref(iters), C.byref(conv)), self.h)
         return cent, labels, int(iters.value), bool(conv.value)
+
+    # -- exchange protocol v4 (see include/gsx.h) ------------------------------------------------------------------------
+    def vote_num_views(self):
+        return int(self._lib.gsx_vote_num_views(self.h))
+
+    def vote_export(self, reserve_bytes=0, blobs=True):
+        """-> (pool device pointer, bytes in use, blobs uint8 (views, 256) or None)."""
+        nv = self.vote_num_views()
+        b = np.empty((nv, 256), np.uint8) if blobs else None
+        ptr, used = C.c_void_p(), C.c_int64()
+        check(self._lib.gsx_vote_export(self.h, int(reserve_bytes), b.ctypes.data if blobs and nv else None, C.byref(ptr),
+                                        C.byref(used)), self.h)
+        return ptr.value, int(used.value), b
+
+    def vote_import(self, part_views, part_offsets, blobs, pool_all_ptr, pool_all_bytes):
+        pv = np.ascontiguousarray(part_views, np.int32)
+        po = np.ascontiguousarray(part_offsets, np.int64)
+        bl = np.ascontiguousarray(blobs, np.uint8)
+        check(self._lib.gsx_vote_import(self.h, len(pv), pv.ctypes.data, po.ctypes.data, bl.ctypes.data if bl.size else None,
+                                        C.c_void_p(pool_all_ptr), int(pool_all_bytes)), self.h)
+
+    def vote_slab_labels(self, slab, slabs):
+        """-> slab size S; the slab's labels (Morton order) are the first S words at keys_device()."""
+        sn = C.c_int64()
+        check(self._lib.gsx_vote_slab_labels(self.h, int(slab), int(slabs), C.byref(sn)), self.h)
+        return int(sn.value)
+
+    def host_threads(self):
+        return int(self._lib.gsx_host_threads(self.h))
 
     def vote_culled(self, reset=False):
         """(wave, view) pairs skipped by the wave culling so far (gsx_vote_culled)."""
@@ -295,6 +369,7 @@ class Context:
 
     def synchronize(self):
         check(self._lib.gsx_synchronize(self.h), self.h)
+        self._keep_alive.clear()
 
     @property
     def stream(self):
@@ -304,6 +379,15 @@ class Context:
     def profile(self, on=True):
         check(self._lib.gsx_profile_enable(self.h, 1 if on else 0), self.h)
         check(self._lib.gsx_profile_reset(self.h), self.h)
+
+    def profile_names(self):
+        out, i = [], 0
+        while True:
+            nm = self._lib.gsx_profile_name(self.h, i)
+            if nm is None:
+                return out
+            out.append(nm.decode())
+            i += 1
 
     def profile_get(self, name):
         n, ms = C.c_int64(), C.c_double()
@@ -348,3 +432,24 @@ def assign_labels_from_maps(gaussians, cameras, segmaps, image_sizes=None, n_cla
     finally:
         if own:
             ctx.close()
+
+
+def host_pack(seg_map, n_classes, tiled=True, coarse=True, threads=1, packed_u8=False):
+    """Test hook, no GPU: the packed form gsx_vote_view stages for a host map -> (bytes u8, coarse_off or -1, bad)."""
+    seg = np.asarray(seg_map)
+    if seg.dtype == np.int64:
+        dt = _lib.GSX_SEG_I64
+    elif seg.dtype == np.uint8:
+        dt = _lib.GSX_SEG_U8 if packed_u8 else _lib.GSX_SEG_U8_LABELS
+    else:
+        seg, dt = seg.astype(np.int32, copy=False), _lib.GSX_SEG_I32
+    seg = np.ascontiguousarray(seg)
+    h, w = seg.shape
+    nbytes, coff, bad = C.c_int64(), C.c_int64(), C.c_int32()
+    L = _lib.lib()
+    check(L.gsx_debug_host_pack(seg.ctypes.data, dt, w, h, n_classes, int(tiled), int(coarse), threads, None, 0, C.byref(nbytes),
+                                C.byref(coff), C.byref(bad)))
+    out = np.zeros(nbytes.value, np.uint8)
+    check(L.gsx_debug_host_pack(seg.ctypes.data, dt, w, h, n_classes, int(tiled), int(coarse), threads, out.ctypes.data, out.size,
+                                C.byref(nbytes), C.byref(coff), C.byref(bad)))
+    return out, coff.value, bool(bad.value)

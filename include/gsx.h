@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define GSX_ABI_VERSION 1
+#define GSX_ABI_VERSION 2
 
 typedef enum gsx_status {
     GSX_OK = 0,
@@ -50,7 +50,9 @@ typedef struct gsx_camera {
 typedef enum gsx_seg_dtype {
     GSX_SEG_I32 = 0, /* int32, values in [-1, n_classes-1]  (YOLO / Mask2Former maps)      */
     GSX_SEG_I64 = 1, /* int64, same range                    (SegFormer argmax)             */
-    GSX_SEG_U8 = 2   /* uint8 holding label+1 (0 = label -1): the compact on-device form   */
+    GSX_SEG_U8 = 2,  /* uint8 holding label+1 (0 = label -1): the compact on-device form   */
+    GSX_SEG_U8_LABELS = 3 /* uint8 holding the label itself, 0 .. n_classes-1 (a class map stored
+                        * as an 8-bit image; it cannot express -1)                          */
 } gsx_seg_dtype;
 
 /* ---------------------------------------------------------------------------------------------
@@ -79,11 +81,11 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "flat_project" (default 1)  the projection as one straight-line block (all rows, both divisions, one predicate at
  *                               the end, one wave-uniform depth early-out) instead of the reference's three early
  *                               returns as divergent branches; same operations on the same operands
- *   "wave_cull"    (default 0)  skip a view for a whole wave when the bounding sphere of its 64 Gaussians lies
+ *   "wave_cull"    (default 1)  skip a view for a whole wave when the bounding sphere of its 64 Gaussians lies
  *                               outside the view's frustum by a safety margin (see gsx_debug_cull_planes).  Skips
- *                               33 % of the (wave, view) pairs of the benchmark scene, bit-identical results, but
- *                               measured 3-5 % SLOWER: the kernel waits on seg-map gathers (which invisible pairs
- *                               never issued), not on arithmetic
+ *                               33 % of the (wave, view) pairs of the benchmark scene, bit-identical results.  On its
+ *                               own it measured 3-5 % slower (the kernel waited on seg-map gathers, which invisible
+ *                               pairs never issued); together with "seg_coarse" it is worth 12 %
  *   "lds_batch"    (default 0)  read the LDS counters of a whole chunk of views in one round trip and
  *                               resolve repeated bins in registers (measured 2.6 % slower: VALU-bound)
  *   "fast_div"     (default 0)  projection through ONE reciprocal with a certified margin; lanes within 2^-20 of a
@@ -147,12 +149,24 @@ int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y)
  * [first_view, first_view + k); total_views is the number of views over ALL ranks (sizes the
  * counters: <= 65535).  Single GPU: first_view = 0, total_views = number of views (upper bound ok). */
 int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t total_views);
-/* seg: HOST pointer, seg_h x seg_w row-major.  img_w,img_h: the PIL image size (dls.py:261-263). */
+/* seg: HOST pointer, seg_h x seg_w row-major.  img_w,img_h: the PIL image size (dls.py:261-263).
+ * The map is read during the call (worker threads narrow it to the u8 on-device form inside pinned memory and
+ * check the label range: GSX_E_RANGE fails THIS call and stages nothing); the DMA into the pool is asynchronous
+ * and nothing is synchronised: 200 calls cost the host pass over the maps, ~2.2 MB of PCIe traffic per 1080p map.
+ * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool. */
 int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
                   int32_t seg_h, int32_t img_w, int32_t img_h);
-/* same, seg is a DEVICE pointer (e.g. the segmentation model's output tensor on this GPU) */
+/* same, seg is a DEVICE pointer (e.g. the segmentation model's output tensor on this GPU): one fused kernel on
+ * the ctx stream (gsx_stream) reads it once and writes both map levels; the caller orders that stream after the
+ * producer of the map and keeps the map alive until the stream has passed (gsx_synchronize, an event, ...).
+ * Nothing is read back here: a label outside [-1, n_classes-1] is recorded on the device and fails the call that
+ * hands out the labels (gsx_vote_finalize, gsx_vote_labels_from_*) with GSX_E_RANGE, naming the view. */
 int gsx_vote_view_device(gsx_ctx* ctx, const gsx_camera* cam, const void* seg_dev, int32_t seg_dtype,
                          int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h);
+/* n device maps of one geometry and dtype, views in array order: 16 maps per kernel launch (a 1080p map is ~2 us
+ * of HBM time, less than a launch).  cams[n], segs_dev[n]. */
+int gsx_vote_views_device(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, const void* const* segs_dev, int32_t seg_dtype,
+                          int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h);
 int32_t gsx_vote_num_views(const gsx_ctx* ctx);
 /* forget accumulated votes but keep the staged views: the next flush/finalize votes them again */
 int gsx_vote_rewind(gsx_ctx* ctx);
@@ -210,6 +224,32 @@ int gsx_vote_tie_resolve(gsx_ctx* ctx, const void* recv_codes_dev);
 int64_t gsx_vote_slab_size(const gsx_ctx* ctx);
 int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev);
 int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out);
+/* ---- protocol v4: views sharded for the hand-over, GAUSSIANS sharded for the vote (bench.py's default for N > 1) ----
+ * The packed maps of 200 1080p views are 0.44 GB in total; the dense vote histogram of 3 M Gaussians is 0.45 GB PER
+ * RANK.  So the maps cross the fabric, not the votes; no option is needed and the tie rule is the single-GPU one.
+ *   rank-local:  gsx_vote_view* for this rank's contiguous, rank-ordered block of views
+ *   exchange 0:  every rank learns all (view count, pool bytes) pairs and all view blobs  [tiny; see gsx_vote_export]
+ *   rank-local:  gsx_vote_export(chunk): chunk = the largest rank's pool bytes; the rank's pool now spans >= chunk
+ *   exchange 1:  all_gather of the pools, chunk bytes per rank, into one caller-owned device buffer
+ *   rank-local:  gsx_vote_import: the ctx now holds ALL views, their maps read from the gathered buffer
+ *                gsx_vote_slab_labels(rank, world): the fused single-GPU kernel over this rank's slab of the Gaussians
+ *                (Morton order) -> slab_size int32 labels at gsx_vote_keys_device()
+ *   exchange 2:  all_gather of the slab labels, then gsx_vote_labels_from_sorted
+ * A view blob is GSX_VIEW_BLOB_BYTES opaque bytes (the library's view descriptor: camera, map geometry, offset inside
+ * the exporting rank's pool); it is only meaningful to another instance of the same library build. */
+#define GSX_VIEW_BLOB_BYTES 256
+/* reserve_bytes: grow this rank's pool to at least that many bytes (the all-gather reads `chunk` bytes from it).
+ * blobs_out (may be NULL): gsx_vote_num_views() * GSX_VIEW_BLOB_BYTES bytes on the host.  *pool_dev: the pool,
+ * valid until the next gsx_vote_view* / gsx_vote_begin; *pool_bytes: bytes in use (a multiple of 256). */
+int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes);
+/* part r contributed part_views[r] views (blobs in part order) whose maps start at byte part_offsets[r] of
+ * pool_all_dev (pool_all_bytes long; caller-owned, must stay alive and unchanged until the labels have been fetched).
+ * Replaces the views staged so far; global view order = part order.  Blobs are validated against the pool size. */
+int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
+                    const void* pool_all_dev, int64_t pool_all_bytes);
+/* votes the Gaussians [slab * S, min(n, (slab+1) * S)) of the Morton order over all staged views, S = *slab_size =
+ * ceil(n / slabs) rounded up to 256; labels (int32, Morton order) at gsx_vote_keys_device()[0 .. S). */
+int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size);
 /* copies of the rank-local planes for tests: counts[bins][n] and first-view codes, widened to u16 */
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out);
 
@@ -291,6 +331,12 @@ int gsx_ply_write(const gsx_ply* ply, const char* path, const int32_t* labels, i
  * which restates the stable counting sort of gs.js:443-457.  Host arrays, sorted in place.
  * ------------------------------------------------------------------------------------------- */
 int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits);
+/* test hook, host only (no context, no GPU): the packed form of one map exactly as gsx_vote_view stages it in
+ * pinned memory - u8 bins in strips of 16 pixel columns (tiled != 0; row-major otherwise) followed, at *coarse_off
+ * (-1: none), by the 4x4-coarsened level.  out == NULL only reports *bytes.  *bad = 1 if a label was out of range. */
+int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
+                        int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
+                        int32_t* bad);
 /* statistics: (wave of 64 Gaussians, view) pairs the vote kernels skipped through the wave culling since the context
  * was created or since the last call with reset != 0 */
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);
@@ -320,7 +366,11 @@ int gsx_kmeans(gsx_ctx* ctx, int64_t n, const float* points, const float* colors
  * ------------------------------------------------------------------------------------------- */
 int gsx_profile_enable(gsx_ctx* ctx, int on);
 int gsx_profile_reset(gsx_ctx* ctx);
-/* name: "vote_fused", "seg_pack", ...; returns launches and total milliseconds since reset */
+/* the index-th kernel name seen since profiling was first enabled, or NULL past the end */
+const char* gsx_profile_name(gsx_ctx* ctx, int32_t index);
+/* worker threads (including the caller) gsx_vote_view packs host maps with; starts the pool if need be */
+int gsx_host_threads(gsx_ctx* ctx);
+/* name: "vote_fused_labels", "seg_pack", ...; returns launches and total milliseconds since reset */
 int gsx_profile_get(gsx_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
 
 #ifdef __cplusplus

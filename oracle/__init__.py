@@ -407,3 +407,101 @@ class NumpySparseShard(NumpySlabShard):
             hit = np.nonzero(rc[:, i])[0]
             out[i] = (int(rc[hit[0], i]) & 0xff) - 1 if len(hit) else -1
         return out
+
+
+# ---- exchange protocol v4 (dist.exchange_labels_gather) ----------------------------------------------------------------
+def pack_map_numpy(seg, n_classes):
+    """The library's on-device form of one segmentation map, restated in numpy (layout documented in
+    csrc/host_pack.hpp / vote.hip): u8 bins (label + 1) in strips of 16 pixel columns (16 B per row, rows padded to
+    a multiple of 8), then at a 256-B aligned offset the 4x4-coarsened level in the same strip layout (a cell = the bin
+    its 16 pixels share, 255 where they differ or the cell sticks out of the map).  -> (bytes, coarse_off)."""
+    seg = np.asarray(seg)
+    h, w = seg.shape
+    bins = (seg.astype(np.int64) + 1).astype(np.uint8)
+    strip = (h + 7) // 8 * 128
+    fine_bytes = strip * ((w + 15) // 16)
+    cw, ch = (w + 3) // 4, (h + 3) // 4
+    cstrip = (ch + 7) // 8 * 128
+    coarse_off = (fine_bytes + 255) // 256 * 256
+    out = np.zeros(coarse_off + cstrip * ((cw + 15) // 16), np.uint8)
+    ys, xs = np.mgrid[0:h, 0:w]
+    out[(xs >> 4) * strip + ys * 16 + (xs & 15)] = bins
+    padded = np.full((ch * 4, cw * 4), -1, np.int64)          # -1 never equals a bin: ragged cells come out mixed
+    padded[:h, :w] = bins
+    cells = padded.reshape(ch, 4, cw, 4).transpose(0, 2, 1, 3).reshape(ch, cw, 16)
+    uniform = (cells == cells[:, :, :1]).all(axis=2) & (cells[:, :, 0] >= 0)
+    cval = np.where(uniform, cells[:, :, 0], 255).astype(np.uint8)
+    cys, cxs = np.mgrid[0:ch, 0:cw]
+    out[coarse_off + (cxs >> 4) * cstrip + (cxs & 15) + cys * 16] = cval
+    return out, coarse_off
+
+
+def unpack_map_numpy(packed, w, h):
+    """Inverse of pack_map_numpy's full-resolution level: int32 labels (h, w)."""
+    strip = (h + 7) // 8 * 128
+    ys, xs = np.mgrid[0:h, 0:w]
+    return packed[(xs >> 4) * strip + ys * 16 + (xs & 15)].astype(np.int32) - 1
+
+
+class NumpyGatherShard:
+    """CPU stand-in for one rank of exchange protocol v4, gloo tests only: packed maps are all-gathered, every rank
+    votes its slab of the Gaussians over all views (here: the C oracle on the unpacked maps), labels are all-gathered.
+    A "blob" is 256 bytes: 24 float64 = fx, fy, width, height, R[9], p[3], seg_w, seg_h, img_w, img_h, pool offset."""
+
+    def __init__(self, positions, cams, segs, img_sizes, n_classes, pack=None):
+        self.pos = np.ascontiguousarray(positions, np.float32)
+        self.n = len(self.pos)
+        self.n_classes = n_classes
+        blobs, chunks, off = [], [], 0
+        for cam, seg, sz in zip(cams, segs, img_sizes):
+            packed = pack(seg) if pack is not None else pack_map_numpy(seg, n_classes)[0]
+            h, w = np.asarray(seg).shape
+            rec = np.zeros(32, np.float64)
+            rec[:2] = cam["fx"], cam["fy"]
+            rec[2:4] = cam["width"], cam["height"]
+            rec[4:13] = np.asarray(cam["rotation"], np.float64).reshape(-1)
+            rec[13:16] = cam["position"]
+            rec[16:21] = w, h, sz[0], sz[1], off
+            blobs.append(rec.view(np.uint8))
+            chunks.append(packed)
+            off += (packed.size + 255) // 256 * 256
+        self._blobs = np.stack(blobs) if blobs else np.zeros((0, 256), np.uint8)
+        self._pool = np.zeros(off, np.uint8)
+        o = 0
+        for c in chunks:
+            self._pool[o:o + c.size] = c
+            o += (c.size + 255) // 256 * 256
+        self.views = None
+
+    def export(self):
+        return self._blobs, self._pool.size
+
+    def pool(self, chunk):
+        out = np.zeros(chunk, np.uint8)
+        out[:self._pool.size] = self._pool
+        return out
+
+    def import_all(self, part_views, part_offsets, blobs, pool_all):
+        recs = np.ascontiguousarray(blobs, np.uint8).reshape(-1, 256).view(np.float64)
+        self.views, k = [], 0
+        for r, nv in enumerate(part_views):
+            for _ in range(int(nv)):
+                rec = recs[k]
+                k += 1
+                cam = {"fx": rec[0], "fy": rec[1], "width": int(rec[2]), "height": int(rec[3]),
+                       "rotation": rec[4:13].reshape(3, 3).tolist(), "position": rec[13:16].tolist()}
+                w, h, iw, ih, off = (int(v) for v in rec[16:21])
+                seg = unpack_map_numpy(pool_all[int(part_offsets[r]) + off:], w, h)
+                self.views.append((cam, seg, (iw, ih)))
+
+    def slab_labels(self, rank, world):
+        sn = ((self.n + world - 1) // world + 255) // 256 * 256 or 256
+        lo, hi = min(self.n, rank * sn), min(self.n, (rank + 1) * sn)
+        out = np.full(sn, -1, np.int32)
+        if hi > lo:
+            cams, segs, sizes = zip(*self.views) if self.views else ((), (), ())
+            out[:hi - lo] = assign_labels(self.pos[lo:hi], list(cams), list(segs), list(sizes), threads=1)
+        return out
+
+    def finish(self, all_labels):
+        return np.asarray(all_labels[:self.n], dtype=np.int32)

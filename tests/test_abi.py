@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/gsx.h but not exported"
     # and the ctypes binding covers exactly the header
     assert names == g._lib.declared_symbols()
-    assert g.lib().gsx_abi_version() == 1
+    assert g.lib().gsx_abi_version() == 2
 
 
 def test_camera_struct_layout():

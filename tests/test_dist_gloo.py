@@ -115,6 +115,47 @@ def test_all_to_all_exchange_equals_reference_labels(case_idx, world):
     assert all(ok for _, ok, _ in res), res
 
 
+def _worker_gather(rank, world, port, case_idx, product_packer, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+        name, pos, cams, segs, sizes, labels = golden_assign_cases()[case_idx]
+        lo, hi = pkg.dist.view_range(len(cams), rank, world)
+        # product_packer: the maps are packed by libgsx's own host packer (gsx_debug_host_pack, no GPU needed), i.e. the
+        # bytes that really cross the fabric; otherwise by the oracle's numpy restatement of the layout
+        labeler = importlib.import_module("3d_gaussian_splatting_project_amd.labeler")
+        pack = (lambda seg: labeler.host_pack(seg, 150, threads=2)[0]) if product_packer else None
+        shard = oracle.NumpyGatherShard(pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], 150, pack=pack)
+        got = pkg.dist.exchange_labels_gather(pkg.dist.HostGatherShard(shard), cap_views=len(cams))
+        out = np.empty(len(pos), np.int32)
+        same = pkg.dist.exchange_labels_gather(pkg.dist.HostGatherShard(shard), out=out, cap_views=len(cams))
+        q.put((rank, bool(np.array_equal(got, labels)) and same is out and bool(np.array_equal(out, labels)), int((got != labels).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case_idx,world,product_packer", [(2, 2, True), (3, 2, False), (4, 2, True), (3, 3, True), (0, 3, False)])
+def test_gather_exchange_equals_reference_labels(case_idx, world, product_packer):
+    """Protocol v4 (all-gather of the packed maps, Gaussian slabs, all-gather of labels), incl. the ties fixture, the
+    mixed-geometry fixture (maps smaller than the image, camera size != image size), 3 ranks, and a rank WITHOUT any
+    view (case 0 has one view: ranks 1 and 2 stage nothing)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() + case_idx * 17 + world) % 2000
+    procs = [ctx.Process(target=_worker_gather, args=(r, world, port, case_idx, product_packer, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+
+
 def test_view_range_is_contiguous_and_ordered():
     pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
     for total in (1, 7, 8, 200, 1601):
@@ -131,3 +172,5 @@ def test_single_process_exchange_is_identity():
     name, pos, cams, segs, sizes, labels = golden_assign_cases()[3]
     shard = oracle.NumpyVoteShard(pos, cams, segs, sizes, 150, 0, len(cams))
     assert np.array_equal(pkg.dist.exchange_labels(pkg.dist.HostVoteShard(shard)), labels)
+    g = oracle.NumpyGatherShard(pos, cams, segs, sizes, 150)
+    assert np.array_equal(pkg.dist.exchange_labels_gather(pkg.dist.HostGatherShard(g)), labels)
