@@ -1,0 +1,23 @@
+// Scaling of the host-side map packer with a PERSISTENT worker pool (the configuration gsx_vote_view runs):
+//   g++ -O3 -std=c++17 -I3d_gaussian_splatting_project_amd/csrc tools/host_pack_scaling.cpp 3d_gaussian_splatting_project_amd/csrc/host_pack.o -o /tmp/hps -lpthread && /tmp/hps <threads> [w h maps]
+#include "host_pack.hpp"
+#include <chrono>
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+using namespace gsx;
+int main(int argc,char**argv){
+  int T = argc>1?atoi(argv[1]):8; int w=argc>2?atoi(argv[2]):1920,h=argc>3?atoi(argv[3]):1080; int M=argc>4?atoi(argv[4]):24;
+  std::vector<std::vector<int32_t>> maps(M);
+  for(int m=0;m<M;++m){ maps[m].resize((size_t)w*h); for(size_t i=0;i<maps[m].size();++i) maps[m][i]=(int)((i/ (97+m)) %151)-1; }
+  MapLayout L = map_layout(w,h,true,true);
+  std::vector<uint8_t> dst(L.map_bytes*4);
+  Workers pool(T);
+  for(int rep=0;rep<3;++rep){
+    auto t0=std::chrono::steady_clock::now();
+    int bad=0;
+    for(int m=0;m<M;++m) bad|=host_pack_map(&pool, maps[m].data(), 0, L, 151, dst.data()+L.map_bytes*(m&3));
+    double dt=std::chrono::duration<double>(std::chrono::steady_clock::now()-t0).count();
+    printf("T=%d: %.3f ms/map, %.1f GB/s source, bad=%d map_bytes=%zu\n",T,dt/M*1e3,(double)M*w*h*4/dt/1e9,bad,L.map_bytes);
+  }
+}
