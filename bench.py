@@ -237,6 +237,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n * total_views / (elapsed / args.steps)
     labels_main = labels_buf.copy()
+    labels_check = None
+    if mode == "gather":
+        # after the import every rank holds every view: a plain single-GPU vote of ALL Gaussians on this rank must give
+        # the labels the exchange assembled from the ranks' slabs (rank-local, no collective)
+        labels_check = bool(np.array_equal(ctx.vote_finalize(), labels_main))
 
     # ---- dominant kernel: HIP-event time on the ctx stream over the timed region, algorithmic bytes / time -----------
     kname = {None: "vote_fused_labels", "gather": "vote_fused_labels", "sparse": "vote_fused_counts"}.get(mode, "vote_fused_planes")
@@ -408,7 +413,8 @@ def main():
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
                        "wave_views_culled_fraction": round(culled_frac, 4),
-                       "setup_seconds": round(setup_s, 1)},
+                       "setup_seconds": round(setup_s, 1),
+                       "exchanged_labels_equal_single_gpu_vote": labels_check},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "vs_cpu_baseline": None if cpu is None else cpu["gpu_speedup_all_cores"],

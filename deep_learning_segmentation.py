@@ -130,17 +130,13 @@ def assign_labels(gaussians, cameras, input_dir, output_dir, model_type="mask2fo
     own = ctx is None
     ctx = ctx or gsx.Context()
     try:
-        if world > 1:
-            # one process per GPU: this rank segments and votes its contiguous block of the processed cameras;
-            # the per-Gaussian vote histogram is then exchanged (dist.py, protocol v3)
-            gsx.dist.configure_a2a(ctx, world)
-            lo, hi = gsx.dist.view_range(len(todo), rank, world)
-        else:
-            lo, hi = 0, len(todo)
-        if hi - lo > 255 and world > 1:
-            raise ValueError("at most 255 views per GPU in the multi-GPU exchange")
+        # one process per GPU: this rank segments and stages its contiguous block of the processed cameras; the packed
+        # maps are then all-gathered and every rank votes its slab of the Gaussians (dist.py, protocol v4).  A rank
+        # may end up without any camera (more GPUs than images): it still takes part in every collective.
+        lo, hi = gsx.dist.view_range(len(todo), rank, world) if world > 1 else (0, len(todo))
+        total = max(1, len(todo))
         ctx.upload_positions(gaussians)
-        ctx.vote_begin(n_classes, lo, max(1, len(todo)))
+        ctx.vote_begin(n_classes, min(lo, total - 1), total)
         for camera, img_path in todo[lo:hi]:
             print(f"Processing image {os.path.basename(img_path)}...")
             if segmap_dir is not None:
@@ -149,17 +145,26 @@ def assign_labels(gaussians, cameras, input_dir, output_dir, model_type="mask2fo
                 seg_map = segment_image(img_path, output_dir, processor, model, device, model_type)
             ctx.vote_view(camera, seg_map, _image_size(img_path))
         if world > 1:
-            return gsx.dist.exchange_labels_sparse(gsx.dist.GpuSparseShard(ctx))
+            return gsx.dist.exchange_labels_gather(gsx.dist.GpuGatherShard(ctx), cap_views=total)
         return ctx.vote_finalize()
     finally:
         if own:
             ctx.close()
 
 
-def _shutdown():
+def _shutdown(failed=False):
+    """Leave a torch.distributed run.  After a failure on THIS rank the peers may be blocked in a collective this rank
+    will never join: no barrier then, the process ends with a non-zero code and the launcher takes the others down."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         import torch.distributed as dist
         if dist.is_initialized():
+            if failed:
+                import sys
+                import traceback
+                traceback.print_exc()
+                sys.stdout.flush()
+                sys.stderr.flush()
+                os._exit(1)
             dist.barrier()
             dist.destroy_process_group()
 
@@ -211,8 +216,10 @@ def main(argv=None):
     try:
         labels = assign_labels(gaussians, cameras, args.input_dir, args.output_dir, model_type=args.model,
                                segmap_dir=args.segmap_dir, n_classes=args.n_classes)
-    finally:
-        _shutdown()
+    except BaseException:
+        _shutdown(failed=True)
+        raise
+    _shutdown()
     if int(os.environ.get("RANK", "0")) != 0:
         return          # every rank holds the same labels; rank 0 writes the file
     print("Saving labeled PLY file...")

@@ -771,27 +771,31 @@ def test_config5_shape_sample(ctx):
     assert np.array_equal(a[sample], want)
 
 
-def test_cli_two_ranks_on_one_gpu(tmp_path):
-    """deep_learning_segmentation.py under torch.distributed.run with 2 ranks sharing this GPU (gloo carries the
-    exchange: functional rehearsal of the multi-GPU CLI path, protocol v3) -> same labelled PLY as the oracle."""
+@pytest.mark.parametrize("ranks,V", [(2, 7), (3, 2)])
+def test_cli_ranks_on_one_gpu(tmp_path, ranks, V):
+    """deep_learning_segmentation.py under torch.distributed.run with several ranks sharing this GPU (gloo carries the
+    exchange: functional rehearsal of the multi-GPU CLI path, protocol v4) -> same labelled PLY as the oracle.
+    (3 ranks, 2 views: the last rank has no camera at all and still takes part in every collective.)  A uint8
+    `_segmap.npy` (a class map stored as an 8-bit image) gives the labels of its int32 copy."""
     import json
     import subprocess
     import sys
     from PIL import Image
     from conftest import ROOT
     pio = importlib.import_module("3d_gaussian_splatting_project_amd.ply_io")
-    n, V, W, H = 30_000, 7, 320, 180
+    n, W, H = 30_000, 320, 180
     pos, cams, segs = scene.make_scene(n, V, W, H, n_classes=20, config_id=51, convention="w2c")
+    segs[0] = np.maximum(segs[0], 0)
     pio.write_vertex_ply(str(tmp_path / "in.ply"), {"x": pos[:, 0], "y": pos[:, 1], "z": pos[:, 2]})
     json.dump(cams, open(tmp_path / "cameras.json", "w"))
     (tmp_path / "img").mkdir()
     (tmp_path / "seg").mkdir()
-    for cam, seg in zip(cams, segs):
-        np.save(tmp_path / "seg" / f"{cam['img_name']}_segmap.npy", seg)
+    for k, (cam, seg) in enumerate(zip(cams, segs)):
+        np.save(tmp_path / "seg" / f"{cam['img_name']}_segmap.npy", seg.astype(np.uint8) if k == 0 else seg)
         Image.new("L", (W, H)).save(tmp_path / "img" / f"{cam['img_name']}.png")
-    env = dict(os.environ, GSX_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29711", os.path.join(ROOT, "deep_learning_segmentation.py"), "--ply_file", str(tmp_path / "in.ply"),
+    env = dict(os.environ, GSX_DIST_BACKEND="gloo", GSX_HOST_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(29711 + ranks), os.path.join(ROOT, "deep_learning_segmentation.py"), "--ply_file", str(tmp_path / "in.ply"),
            "--camera_file", str(tmp_path / "cameras.json"), "--input_dir", str(tmp_path / "img"), "--output_dir",
            str(tmp_path / "out"), "--output_file", str(tmp_path / "out.ply"), "--model", "segformer", "--segmap_dir",
            str(tmp_path / "seg"), "--n_classes", "20"]
