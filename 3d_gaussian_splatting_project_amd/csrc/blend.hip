@@ -8,6 +8,11 @@
 // per 1080p view of the 3 M-splat scene — the pairs that matter come from splats wider than a quadrant,
 // so the test is pure overhead; removed.)  Compiled with -ffp-contract=off: the operations that
 // decide `discard` round exactly like the oracle's; the accumulation uses explicit fmaf.
+//
+// A frame is blended in depth PHASES (render.hip): a phase's kernel continues from the image the previous phase left
+// (first phase: the cleared canvas), marks the tiles whose every pixel has become opaque (`sat`: the next phases do not
+// even bin splats into them), and the last phase appends the dropped-splat epilogue.  Tiles without pairs in a middle
+// phase return at once.
 #include <hip/hip_runtime.h>
 
 #include "gsx_ctx.hpp"
@@ -63,7 +68,8 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
                                                               const float2* __restrict__ rec2, int W, int H, int tiles_x,
                                                               const int* __restrict__ dropped, long long n,
                                                               unsigned long long* __restrict__ consumed,
-                                                              float4* __restrict__ image) {
+                                                              float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
+                                                              int last) {
     __shared__ float4 s0[kBlendThreads];
     __shared__ float4 s1[kBlendThreads];
     __shared__ float2 s2[kBlendThreads];
@@ -74,9 +80,15 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     const bool inside = px < W && py < H;
     const float fxp = (float)px + 0.5f;               // pixel centre, GL window coordinates
     const float fyp = (float)H - ((float)py + 0.5f);  // window y is up; image row py counts from the top
-    Accum acc{0.f, 0.f, 0.f, 0.f};                    // gl.clear to (0,0,0,0), gs.js:1608
     const int2 range = ranges[tile];
+    if (!first && !last && (range.y <= range.x || sat[tile])) return;  // nothing of this phase reaches the tile
+    Accum acc{0.f, 0.f, 0.f, 0.f};                    // gl.clear to (0,0,0,0), gs.js:1608
+    if (!first && inside) {
+        const float4 prev = image[(size_t)py * W + px];
+        acc = Accum{prev.x, prev.y, prev.z, prev.w};
+    }
     int staged = 0;  // list entries this tile actually read
+    bool opaque = false;
     for (int base = range.x; base < range.y; base += kBlendThreads) {
         const int cnt = min(kBlendThreads, range.y - base);
         __syncthreads();
@@ -91,11 +103,13 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
         staged += cnt;
         // every further fragment is weighted by (1 - dst.a): once that is < 1e-5 on the whole tile the
         // rest of the list changes no channel by more than 1e-5 (the parity tolerance is 1e-4)
-        if (__syncthreads_and(!inside || acc.a > 1.0f - 1.0e-5f)) break;
+        opaque = __syncthreads_and(!inside || acc.a > 1.0f - 1.0e-5f) != 0;
+        if (opaque) break;
     }
+    if (opaque && threadIdx.x == 0) sat[tile] = 1;
     // runSort leaves the slots of the splats it drops (bucket 65536) at 0: splat 0 is drawn again,
     // last, once per dropped splat (gs.js:453-457 + 1076-1077, 1609)
-    const int nd = n > 0 ? *dropped : 0;
+    const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
         const float4 r0 = rec0[0];
         const float4 r1 = rec1[0];
@@ -155,7 +169,8 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
                                                                 const float2* __restrict__ rec2, int W, int H, int tiles_x,
                                                                 const int* __restrict__ dropped, long long n,
                                                                 unsigned long long* __restrict__ consumed,
-                                                                float4* __restrict__ image) {
+                                                                float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
+                                                                int last) {
     __shared__ float4 s0[kBlend2Chunk];
     __shared__ float4 s1[kBlend2Chunk];
     __shared__ float2 s2[kBlend2Chunk];
@@ -168,9 +183,17 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     f2 fyp;
     fyp.x = (float)H - ((float)py0 + 0.5f);
     fyp.y = (float)H - ((float)py1 + 0.5f);
-    Accum2 acc{};
     const int2 range = ranges[tile];
+    if (!first && !last && (range.y <= range.x || sat[tile])) return;  // nothing of this phase reaches the tile
+    Accum2 acc{};
+    if (!first) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p0 = in0 ? image[(size_t)py0 * W + px] : z, p1 = in1 ? image[(size_t)py1 * W + px] : z;
+        acc.r.x = p0.x, acc.g.x = p0.y, acc.b.x = p0.z, acc.a.x = p0.w;
+        acc.r.y = p1.x, acc.g.y = p1.y, acc.b.y = p1.z, acc.a.y = p1.w;
+    }
     int staged = 0;
+    bool opaque = false;
     for (int base = range.x; base < range.y; base += kBlend2Chunk) {
         const int cnt = min(kBlend2Chunk, range.y - base);
         __syncthreads();
@@ -194,9 +217,11 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
         for (; k < cnt; ++k) blend_one2(acc, fxp, fyp, s0[k], s1[k], s2[k]);
         staged += cnt;
         const bool done0 = !in0 || acc.a.x > 1.0f - 1.0e-5f, done1 = !in1 || acc.a.y > 1.0f - 1.0e-5f;
-        if (__syncthreads_and(done0 && done1)) break;
+        opaque = __syncthreads_and(done0 && done1) != 0;
+        if (opaque) break;
     }
-    const int nd = n > 0 ? *dropped : 0;
+    if (opaque && threadIdx.x == 0) sat[tile] = 1;
+    const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
         const float4 r0 = rec0[0];
         const float4 r1 = rec1[0];
@@ -224,7 +249,8 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
                                                                 const float2* __restrict__ rec2, int W, int H, int tiles_x,
                                                                 const int* __restrict__ dropped, long long n,
                                                                 unsigned long long* __restrict__ consumed,
-                                                                float4* __restrict__ image) {
+                                                                float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
+                                                                int last) {
     __shared__ float4 s0[kBlend4Chunk];
     __shared__ float4 s1[kBlend4Chunk];
     __shared__ float2 s2[kBlend4Chunk];
@@ -239,9 +265,20 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     fyB.x = (float)H - ((float)(row + 4) + 0.5f);
     fyB.y = (float)H - ((float)(row + 12) + 0.5f);
     const bool in[4] = {px < W && row < H, px < W && row + 8 < H, px < W && row + 4 < H, px < W && row + 12 < H};
-    Accum2 accA{}, accB{};
     const int2 range = ranges[tile];
+    if (!first && !last && (range.y <= range.x || sat[tile])) return;  // nothing of this phase reaches the tile
+    Accum2 accA{}, accB{};
+    if (!first) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p0 = in[0] ? image[(size_t)row * W + px] : z, p1 = in[1] ? image[(size_t)(row + 8) * W + px] : z;
+        const float4 p2 = in[2] ? image[(size_t)(row + 4) * W + px] : z, p3 = in[3] ? image[(size_t)(row + 12) * W + px] : z;
+        accA.r.x = p0.x, accA.g.x = p0.y, accA.b.x = p0.z, accA.a.x = p0.w;
+        accA.r.y = p1.x, accA.g.y = p1.y, accA.b.y = p1.z, accA.a.y = p1.w;
+        accB.r.x = p2.x, accB.g.x = p2.y, accB.b.x = p2.z, accB.a.x = p2.w;
+        accB.r.y = p3.x, accB.g.y = p3.y, accB.b.y = p3.z, accB.a.y = p3.w;
+    }
     int staged = 0;
+    bool opaque = false;
     for (int base = range.x; base < range.y; base += kBlend4Chunk) {
         const int cnt = min(kBlend4Chunk, range.y - base);
         __syncthreads();
@@ -274,9 +311,11 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
         const float lim = 1.0f - 1.0e-5f;
         const bool done = (!in[0] || accA.a.x > lim) && (!in[1] || accA.a.y > lim) && (!in[2] || accB.a.x > lim) &&
                           (!in[3] || accB.a.y > lim);
-        if (__syncthreads_and(done)) break;
+        opaque = __syncthreads_and(done) != 0;
+        if (opaque) break;
     }
-    const int nd = n > 0 ? *dropped : 0;
+    if (opaque && threadIdx.x == 0) sat[tile] = 1;
+    const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
         const float4 r0 = rec0[0];
         const float4 r1 = rec1[0];
@@ -293,9 +332,8 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
 }
 
-int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
-                 unsigned long long* consumed_dev) {
-    const uint32_t* vals = c->r_sorted_in ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>();
+int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
+                 unsigned long long* consumed_dev, uint8_t* sat, int first_phase, int last_phase) {
     const int ntiles = tiles_x * tiles_y;
     const uint32_t* order = nullptr;
     if (c->opt_tile_lpt && c->r_P > 0 && ntiles > 256) {
@@ -313,20 +351,16 @@ int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* drop
     if (c->opt_blend_pk2 == 2) {
         hipLaunchKernelGGL(blend4_kernel, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                           (long long)c->rn, consumed_dev, c->r_image.as<float4>());
-        GSX_HIP(c, hipGetLastError());
-        return GSX_OK;
-    }
-    if (c->opt_blend_pk2) {
+                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+    } else if (c->opt_blend_pk2) {
         hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                           (long long)c->rn, consumed_dev, c->r_image.as<float4>());
-        GSX_HIP(c, hipGetLastError());
-        return GSX_OK;
+                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+    } else {
+        hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
+                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     }
-    hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
-                       c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                       (long long)c->rn, consumed_dev, c->r_image.as<float4>());
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }

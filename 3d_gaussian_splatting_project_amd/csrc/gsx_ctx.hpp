@@ -125,7 +125,7 @@ struct Ctx {
     int opt_local_codes = 0;   // see Ctx::local_codes
     int opt_lds_batch = 0;     // read a chunk's LDS counters in one round trip (repeats resolved in registers)
     int opt_blend_pk2 = 1;     // rasterizer: two pixels per thread, packed fp32 maths
-    int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %, net slower)
+    int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %; the test costs more than the sort saves)
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B
     int opt_fast_div = 0;      // certified single-reciprocal projection with exact fallback (bit-identical, not faster)
@@ -189,7 +189,11 @@ struct Ctx {
     DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
     DevBuf r_tile_order;                 // blend launch order (longest list first)
     int r_sorted_in = 0;
-    uint32_t r_P = 0;                    // (tile, splat) pairs of the last view
+    DevBuf r_sat;                        // u8 per tile: every pixel is opaque (1 - alpha < 1e-5): later depth phases skip it
+    int opt_render_phases = 2;           // depth phases per frame (1 = bin and sort every pair at once)
+    int opt_render_phase_ratio = 4;      // phase p ends at n / ratio^(K-1-p) splats (front to back)
+    unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
+    size_t r_pair_cap = 0;               // capacity (pairs) of r_keys*/r_vals*: grown when a phase overflows it, the frame is redone
     unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)
     DevBuf r_d0, r_d1, r_d2, r_d3;       // level-1 sort ping-pong (bucket, splat)
 
@@ -240,6 +244,8 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
 // sort.hip
 int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
                      int* result_in);
+int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
+                         const unsigned long long* n_dev, int bits, int* result_in);
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
 int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, const int64_t* init_index, int max_iter,

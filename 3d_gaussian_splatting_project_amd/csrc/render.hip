@@ -163,8 +163,9 @@ __global__ __launch_bounds__(kRB) void splat_pack_kernel(const uint32_t* __restr
 }
 
 // ---- spherical-harmonics colour (degrees 1..3; not in the reference, see oracle/render_oracle.c) ----------
-// coefficients re-laid at upload as coef[k][i][c] (k = 0 is f_dc), importance order: per view every
-// thread reads its K triples from K coalesced planes.
+// coefficients re-laid at upload as coef[k][c][i] (k = 0 is f_dc), importance order: per view every thread reads
+// its 3K coefficients from 3K planes, each load a fully used 256-B run per wave (as [k][i][c] the 12-byte stride
+// made every load instruction straddle six lines).
 __global__ __launch_bounds__(kRB) void sh_pack_kernel(const uint32_t* __restrict__ order, long long n,
                                                        const float* __restrict__ f_dc, const float* __restrict__ f_rest,
                                                        int K, float* __restrict__ coef) {
@@ -173,22 +174,19 @@ __global__ __launch_bounds__(kRB) void sh_pack_kernel(const uint32_t* __restrict
     const long long r = order[j];
     const int K1 = K - 1;
     for (int c = 0; c < 3; ++c) {
-        coef[((size_t)0 * n + j) * 3 + c] = f_dc[3 * r + c];
-        for (int k = 1; k < K; ++k) coef[((size_t)k * n + j) * 3 + c] = f_rest[(size_t)r * 3 * K1 + (size_t)c * K1 + (k - 1)];
+        coef[((size_t)0 * 3 + c) * n + j] = f_dc[3 * r + c];
+        for (int k = 1; k < K; ++k) coef[((size_t)k * 3 + c) * n + j] = f_rest[(size_t)r * 3 * K1 + (size_t)c * K1 + (k - 1)];
     }
 }
 
-__global__ __launch_bounds__(kRB) void sh_color_kernel(const uint4* __restrict__ tex, long long n,
-                                                        const float* __restrict__ coef, int deg, float cpx, float cpy,
-                                                        float cpz, float* __restrict__ rgb) {
-    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (i >= n) return;
+// colour of one splat seen from the camera position: clamp(0.5 + SH(dir), 0, 1) per channel
+__device__ __forceinline__ void sh_color(const float* __restrict__ coef, long long n, long long i, int deg, float px, float py,
+                                         float pz, float cpx, float cpy, float cpz, float rgb[3]) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
     const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                          -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
-    const uint4 t = tex[2 * i];
-    const float dx = __uint_as_float(t.x) - cpx, dy = __uint_as_float(t.y) - cpy, dz = __uint_as_float(t.z) - cpz;
+    const float dx = px - cpx, dy = py - cpy, dz = pz - cpz;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
     float b[16];
@@ -214,15 +212,15 @@ __global__ __launch_bounds__(kRB) void sh_color_kernel(const uint4* __restrict__
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (k < K) {
-            const float* p = coef + ((size_t)k * n + i) * 3;
+            const float* p = coef + (size_t)k * 3 * n + i;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * p[c] : acc[c] + b[k] * p[c];
+            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * p[(size_t)c * n] : acc[c] + b[k] * p[(size_t)c * n];
         }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = acc[c] + 0.5f;
-        rgb[3 * i + c] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        rgb[c] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
     }
 }
 
@@ -234,36 +232,6 @@ struct ViewUniforms {
     float fx, fy, W, H;
     int tiles_x, tiles_y;
 };
-
-// depth = ((vp[2]*x + vp[6]*y + vp[10]*z) * 4096) | 0 and its min / max  (gs.js:436-441)
-// grid-stride over the splats; one atomic pair per workgroup (same-address atomics serialise in L2)
-__global__ __launch_bounds__(kRB) void depth_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
-                                                     int* __restrict__ depth, int* __restrict__ minmax) {
-    __shared__ int slo[4], shi[4];
-    int lo = 2147483647, hi = -2147483647 - 1;
-    for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
-        const uint4 t = tex[2 * i];
-        const double x = (double)__uint_as_float(t.x), y = (double)__uint_as_float(t.y), z = (double)__uint_as_float(t.z);
-        const int d = js_toint32((u.vp2 * x + u.vp6 * y + u.vp10 * z) * 4096.0);
-        depth[i] = d;
-        lo = min(lo, d);
-        hi = max(hi, d);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, __shfl_xor(lo, o));
-        hi = max(hi, __shfl_xor(hi, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        slo[threadIdx.x >> 6] = lo;
-        shi[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&minmax[0], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
-        atomicMax(&minmax[1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
-    }
-}
 
 // Exact tile culling.  A pixel takes a fragment of the splat iff q(d) = (d.g0)^2 + (d.g1)^2 <= 4 for its
 // centre's offset d from the splat centre (A = -q, `discard` if A < -4).  q is a convex quadratic, so its
@@ -295,118 +263,158 @@ __device__ __forceinline__ bool tile_touches(float cx, float cy, float g0x, floa
     return !(q > 4.04f);  // NaN keeps the tile
 }
 
-// bucket (gs.js:443-447) + vertex shader (gs.js:696-750) + tile rectangle
-__global__ __launch_bounds__(kRB) void preprocess_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
-                                                          const int* __restrict__ depth, const int* __restrict__ minmax,
-                                                          const float* __restrict__ sh_rgb /* n x 3 or null */,
-                                                          float4* __restrict__ rec0, float4* __restrict__ rec1,
-                                                          float2* __restrict__ rec2, uint32_t* __restrict__ bucket,
-                                                          uint32_t* __restrict__ tile_rect, uint32_t* __restrict__ tile_count,
-                                                          int* __restrict__ dropped, int exact_cull) {
-    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (i >= n) return;
-    const double minDepth = (double)minmax[0], maxDepth = (double)minmax[1];
-    const double depthInv = (256.0 * 256.0) / (maxDepth - minDepth);
-    const int b = js_toint32(((double)depth[i] - minDepth) * depthInv);
-    uint32_t count = 0, rect = 0;
-    const bool in_range = b >= 0 && b < 65536;  // the JS's typed arrays silently drop anything else
-    bucket[i] = in_range ? (uint32_t)b : 65536u;
-    if (!in_range) atomicAdd(dropped, 1);
+static constexpr uint32_t kEmptyRect = 1u;  // tx0 = 1 > tx1 = 0: covers no tile
 
-    // ---- vertex shader, fp32 ----
-    const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
-    const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
-    float cam[4], p2[4];
+// One pass over the texel pairs per view: depth key (gs.js:436-441: ((vp2 x + vp6 y + vp10 z) * 4096) | 0, fp64, and
+// its min / max over ALL splats), vertex shader (gs.js:696-750, fp32 in the oracle's operation order), colour (the
+// reference's rgba8, or the float SH colour for the splats that are actually drawn) and the tile rectangle of the
+// ellipse's bounding box.  One atomic pair per workgroup for the depth range (same-address atomics serialise in L2).
+__global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
+                                                   const float* __restrict__ sh_coef, int sh_deg, float cpx, float cpy, float cpz,
+                                                   int* __restrict__ depth, int* __restrict__ minmax,
+                                                   float4* __restrict__ rec0, float4* __restrict__ rec1,
+                                                   float2* __restrict__ rec2, uint32_t* __restrict__ tile_rect) {
+    __shared__ int slo[4], shi[4];
+    int lo = 2147483647, hi = -2147483647 - 1;
+    // grid-stride: the launch is capped at 2048 workgroups, i.e. 4096 same-address atomics per frame (one pair per
+    // workgroup of a 12 k-workgroup launch kept the L2 busy for 0.2 ms after the last wave had finished)
+    for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
+        const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
+        const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
+        const int d = js_toint32((u.vp2 * (double)cx_ + u.vp6 * (double)cy_ + u.vp10 * (double)cz_) * 4096.0);
+        depth[i] = d;
+        lo = min(lo, d);
+        hi = max(hi, d);
+        uint32_t rect = kEmptyRect;
+        // ---- vertex shader, fp32 ----
+        float cam[4], p2[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) cam[k] = u.view[k] * cx_ + u.view[4 + k] * cy_ + u.view[8 + k] * cz_ + u.view[12 + k] * 1.0f;
+        for (int k = 0; k < 4; ++k) cam[k] = u.view[k] * cx_ + u.view[4 + k] * cy_ + u.view[8 + k] * cz_ + u.view[12 + k] * 1.0f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) p2[k] = u.proj[k] * cam[0] + u.proj[4 + k] * cam[1] + u.proj[8 + k] * cam[2] + u.proj[12 + k] * cam[3];
-    const float clip = 1.2f * p2[3];
-    bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-    float2 r2 = make_float2(0.f, 0.f);
-    if (drawn) {
-        const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
-        const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
-        const float u3x = half_to_float(t1.z & 0xffffu), u3y = half_to_float(t1.z >> 16);
-        const float V[3][3] = {{u1x, u1y, u2x}, {u1y, u2y, u3x}, {u2x, u3x, u3y}};
-        const float ja = u.fx / cam[2], jb = -(u.fx * cam[0]) / (cam[2] * cam[2]);
-        const float jc = -u.fy / cam[2], jd = (u.fy * cam[1]) / (cam[2] * cam[2]);
-        float ta[3], tb[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            ta[k] = u.view[4 * k + 0] * ja + u.view[4 * k + 1] * 0.0f + u.view[4 * k + 2] * jb;
-            tb[k] = u.view[4 * k + 0] * 0.0f + u.view[4 * k + 1] * jc + u.view[4 * k + 2] * jd;
-        }
-        float a0[3], a1[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a0[k] = ta[0] * V[k][0] + ta[1] * V[k][1] + ta[2] * V[k][2];
-            a1[k] = tb[0] * V[k][0] + tb[1] * V[k][1] + tb[2] * V[k][2];
-        }
-        const float c00 = a0[0] * ta[0] + a0[1] * ta[1] + a0[2] * ta[2];
-        const float c01 = a1[0] * ta[0] + a1[1] * ta[1] + a1[2] * ta[2];
-        const float c11 = a1[0] * tb[0] + a1[1] * tb[1] + a1[2] * tb[2];
-        const float mid = (c00 + c11) / 2.0f;
-        const float hx = (c00 - c11) / 2.0f;
-        const float radius = sqrtf(hx * hx + c01 * c01);
-        const float l1 = mid + radius, l2 = mid - radius;
-        if (l2 < 0.0f) drawn = false;  // gs.js:736
-        const float dx = c01, dy = l1 - c00;
-        const float dl = sqrtf(dx * dx + dy * dy);
-        const float ux = dx / dl, uy = dy / dl;
-        const float s1 = fminf(sqrtf(2.0f * l1), 1024.0f), s2 = fminf(sqrtf(2.0f * l2), 1024.0f);
-        const float mx = s1 * ux, my = s1 * uy;    // majorAxis
-        const float nx = s2 * uy, ny = s2 * -ux;   // minorAxis
-        float fade = p2[2] / p2[3] + 1.0f;
-        fade = fade < 0.0f ? 0.0f : (fade > 1.0f ? 1.0f : fade);
-        float col[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
-        if (sh_rgb) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) col[k] = fade * sh_rgb[3 * i + k];
-        }
-        const float ndcx = p2[0] / p2[3], ndcy = p2[1] / p2[3];
-        const float wcx = (ndcx + 1.0f) * 0.5f * u.W;  // GL window coordinates, y up
-        const float wcy = (ndcy + 1.0f) * 0.5f * u.H;
-        const float m2 = mx * mx + my * my, n2 = nx * nx + ny * ny;
-        const float big = 3.0e38f;
-        if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
+        for (int k = 0; k < 4; ++k) p2[k] = u.proj[k] * cam[0] + u.proj[4 + k] * cam[1] + u.proj[8 + k] * cam[2] + u.proj[12 + k] * cam[3];
+        const float clip = 1.2f * p2[3];
+        bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+        float2 r2 = make_float2(0.f, 0.f);
         if (drawn) {
-            r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
-            r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
-            // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
-            const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
-            r2 = make_float2(col[2], col[3]);
-            const float top = u.H - wcy;  // image row coordinate of the centre
-            int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
-            int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
-            x0 = max(x0, 0);
-            y0 = max(y0, 0);
-            x1 = min(x1, (int)u.W - 1);
-            y1 = min(y1, (int)u.H - 1);
-            if (x1 >= x0 && y1 >= y0 && in_range) {
-                const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
-                rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
-                if (exact_cull && (tx1 > tx0 || ty1 > ty0)) {
-                    for (uint32_t ty = ty0; ty <= ty1; ++ty)
-                        for (uint32_t tx = tx0; tx <= tx1; ++tx)
-                            count += tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, u.H, tx, ty) ? 1u : 0u;
-                } else {
-                    count = (tx1 - tx0 + 1) * (ty1 - ty0 + 1);
+            const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
+            const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
+            const float u3x = half_to_float(t1.z & 0xffffu), u3y = half_to_float(t1.z >> 16);
+            const float V[3][3] = {{u1x, u1y, u2x}, {u1y, u2y, u3x}, {u2x, u3x, u3y}};
+            const float ja = u.fx / cam[2], jb = -(u.fx * cam[0]) / (cam[2] * cam[2]);
+            const float jc = -u.fy / cam[2], jd = (u.fy * cam[1]) / (cam[2] * cam[2]);
+            float ta[3], tb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ta[k] = u.view[4 * k + 0] * ja + u.view[4 * k + 1] * 0.0f + u.view[4 * k + 2] * jb;
+                tb[k] = u.view[4 * k + 0] * 0.0f + u.view[4 * k + 1] * jc + u.view[4 * k + 2] * jd;
+            }
+            float a0[3], a1[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a0[k] = ta[0] * V[k][0] + ta[1] * V[k][1] + ta[2] * V[k][2];
+                a1[k] = tb[0] * V[k][0] + tb[1] * V[k][1] + tb[2] * V[k][2];
+            }
+            const float c00 = a0[0] * ta[0] + a0[1] * ta[1] + a0[2] * ta[2];
+            const float c01 = a1[0] * ta[0] + a1[1] * ta[1] + a1[2] * ta[2];
+            const float c11 = a1[0] * tb[0] + a1[1] * tb[1] + a1[2] * tb[2];
+            const float mid = (c00 + c11) / 2.0f;
+            const float hx = (c00 - c11) / 2.0f;
+            const float radius = sqrtf(hx * hx + c01 * c01);
+            const float l1 = mid + radius, l2 = mid - radius;
+            if (l2 < 0.0f) drawn = false;  // gs.js:736
+            const float dx = c01, dy = l1 - c00;
+            const float dl = sqrtf(dx * dx + dy * dy);
+            const float ux = dx / dl, uy = dy / dl;
+            const float s1 = fminf(sqrtf(2.0f * l1), 1024.0f), s2 = fminf(sqrtf(2.0f * l2), 1024.0f);
+            const float mx = s1 * ux, my = s1 * uy;    // majorAxis
+            const float nx = s2 * uy, ny = s2 * -ux;   // minorAxis
+            float fade = p2[2] / p2[3] + 1.0f;
+            fade = fade < 0.0f ? 0.0f : (fade > 1.0f ? 1.0f : fade);
+            const float ndcx = p2[0] / p2[3], ndcy = p2[1] / p2[3];
+            const float wcx = (ndcx + 1.0f) * 0.5f * u.W;  // GL window coordinates, y up
+            const float wcy = (ndcy + 1.0f) * 0.5f * u.H;
+            const float m2 = mx * mx + my * my, n2 = nx * nx + ny * ny;
+            const float big = 3.0e38f;
+            if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
+            if (drawn) {
+                // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
+                const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
+                const float top = u.H - wcy;  // image row coordinate of the centre
+                int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
+                int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
+                x0 = max(x0, 0);
+                y0 = max(y0, 0);
+                x1 = min(x1, (int)u.W - 1);
+                y1 = min(y1, (int)u.H - 1);
+                if (x1 >= x0 && y1 >= y0) {
+                    const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
+                    rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
+                    // the colour is only needed for splats that reach a pixel: 192 B of SH coefficients per splat.
+                    // (Deferring it further, to the splats a depth phase really bins, was measured: those are visited in
+                    // DEPTH order, the coefficient reads become gathers and cost 9x what the skipped splats save.)
+                    float col[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
+                    if (sh_coef) {
+                        float rgb[3];
+                        sh_color(sh_coef, n, i, sh_deg, cx_, cy_, cz_, cpx, cpy, cpz, rgb);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) col[k] = fade * rgb[k];
+                    }
+                    r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
+                    r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
+                    r2 = make_float2(col[2], col[3]);
                 }
             }
         }
+        rec0[i] = r0;
+        rec1[i] = r1;
+        rec2[i] = r2;
+        tile_rect[i] = rect;
     }
-    rec0[i] = r0;
-    rec1[i] = r1;
-    rec2[i] = r2;
-    tile_rect[i] = rect;
-    tile_count[i] = count;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&minmax[0], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
+        atomicMax(&minmax[1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
+    }
 }
 
-// ---- exclusive scan of u32 (3 launches: tile sums, scan of sums, downsweep) ---------------------------------
+// 16-bit depth bucket (gs.js:443-447) once the depth range is known; doubles as the (key, value) initialisation of the
+// level-1 sort.  The JS's typed arrays silently drop a bucket outside [0, 65535] (the farthest splat always gets
+// 65536): such a splat is never drawn, it sorts to the end and loses its tile rectangle here.
+__global__ __launch_bounds__(kRB) void bucket_kernel(const int* __restrict__ depth, long long n, const int* __restrict__ minmax,
+                                                      uint32_t* __restrict__ bucket, uint32_t* __restrict__ key,
+                                                      uint32_t* __restrict__ idx, uint32_t* __restrict__ tile_rect,
+                                                      int* __restrict__ dropped) {
+    const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
+    bool drop = false;
+    if (i < n) {
+        const double minDepth = (double)minmax[0], maxDepth = (double)minmax[1];
+        const double depthInv = (256.0 * 256.0) / (maxDepth - minDepth);
+        const int b = js_toint32(((double)depth[i] - minDepth) * depthInv);
+        const bool in_range = b >= 0 && b < 65536;
+        const uint32_t v = in_range ? (uint32_t)b : 65536u;
+        bucket[i] = v;
+        key[i] = in_range ? v : 65535u;  // 16-bit sort key: a dropped splat covers no tile, where it sorts does not matter
+        idx[i] = (uint32_t)i;
+        drop = !in_range;
+        if (drop) tile_rect[i] = kEmptyRect;
+    }
+    const unsigned long long m = __ballot(drop);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(dropped, (int)__popcll(m));
+}
+
+// ---- exclusive scan of u32 (2 launches: tile sums; downsweep, every workgroup adding up the sums before its own) -----
 static constexpr int kScanItems = 16;
 static constexpr int kScanTile = kRB * kScanItems;
 
@@ -440,23 +448,20 @@ __global__ __launch_bounds__(kRB) void scan_sums_kernel(const uint32_t* __restri
     if (threadIdx.x == 0) sums[blockIdx.x] = total;
 }
 
-__global__ __launch_bounds__(kRB) void scan_top_kernel(uint32_t* __restrict__ sums, int m, uint32_t* __restrict__ grand) {
-    __shared__ uint32_t wsum[4];
-    uint32_t carry = 0;
-    for (int t0 = 0; t0 < m; t0 += kRB) {
-        const int t = t0 + threadIdx.x;
-        const uint32_t v = t < m ? sums[t] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, wsum, total);
-        if (t < m) sums[t] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) *grand = carry;
-}
-
+// sums: one u32 per workgroup (a few hundred): each workgroup re-adds the ones before it instead of a third launch.
+// The last workgroup also writes the grand total (64 bit: the pair count of a close-up view can pass 2^32).
 __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restrict__ in, long long n,
-                                                         const uint32_t* __restrict__ sums, uint32_t* __restrict__ out) {
+                                                         const uint32_t* __restrict__ sums, uint32_t* __restrict__ out,
+                                                         unsigned long long* __restrict__ grand) {
     __shared__ uint32_t wsum[4];
+    __shared__ unsigned long long wbase[4];
+    unsigned long long before = 0;
+    for (int t = threadIdx.x; t < (int)blockIdx.x; t += kRB) before += sums[t];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if ((threadIdx.x & 63) == 0) wbase[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const unsigned long long block_base = wbase[0] + wbase[1] + wbase[2] + wbase[3];
     const long long base = (long long)blockIdx.x * kScanTile + (long long)threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
     uint32_t s = 0;
@@ -466,112 +471,142 @@ __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restri
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = sums[blockIdx.x] + block_exclusive_scan(s, wsum, total);
+    uint32_t run = (uint32_t)block_base + block_exclusive_scan(s, wsum, total);  // offsets are only used when the total fits 31 bits
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) {
         if (base + k < n) out[base + k] = run;
         run += v[k];
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *grand = block_base + total;
 }
 
-// ---- two-level ordering ------------------------------------------------------------------------------
-// The reference orders ALL splats by (bucket, index) (stable counting sort, gs.js:450-457).  Level 1 sorts
-// the n splats by bucket (17 bits, stable); level 2 emits their (tile, splat) pairs in that order and
-// sorts the P pairs by tile only (stable): inside a tile the pairs keep the (bucket, index) order.
-__global__ __launch_bounds__(kRB) void iota2_kernel(uint32_t* __restrict__ idx, long long n) {
-    const long long r = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (r < n) idx[r] = (uint32_t)r;
-}
-
-__global__ __launch_bounds__(kRB) void gather_count_kernel(const uint32_t* __restrict__ by_depth, long long n,
-                                                            const uint32_t* __restrict__ tile_count,
-                                                            uint32_t* __restrict__ out) {
-    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
-    if (j < n) out[j] = tile_count[by_depth[j]];
-}
-
-// Wave-cooperative emission.  The 64 splats of a wave own one contiguous stretch of the pair arrays
-// (their offsets are an exclusive scan in depth order), so the lanes write that stretch element by element:
-// a lane finds the splat owning its element by a binary search over the wave's offsets (shuffles) and
-// derives the tile from the element's rank inside the splat's rectangle.  Stores are coalesced and a splat
-// covering 4000 tiles no longer serialises one lane.
-__global__ __launch_bounds__(kRB) void emit_kernel(long long n, const uint32_t* __restrict__ by_depth,
-                                                    const uint32_t* __restrict__ tile_rect,
-                                                    const uint32_t* __restrict__ count_sorted,
-                                                    const uint32_t* __restrict__ offset, int tiles_x,
-                                                    const float4* __restrict__ rec0, const float4* __restrict__ rec1, float H,
-                                                    int exact_cull, uint32_t* __restrict__ keys,
-                                                    uint32_t* __restrict__ vals) {
-    const long long j = (long long)blockIdx.x * kRB + threadIdx.x;
+// ---- binning ---------------------------------------------------------------------------------------------------------
+// The reference orders ALL splats by (bucket, index) (stable counting sort, gs.js:450-457).  Level 1 sorts the n splats
+// by bucket (16 bits, stable); level 2 emits their (tile, splat) pairs in that order and sorts the pairs by tile only
+// (stable): inside a tile the pairs keep the (bucket, index) order.
+//
+// Wave-cooperative binning.  The 64 splats of a wave (consecutive in depth order) span a list of CANDIDATE tiles: the
+// concatenation of their tile rectangles.  The lanes walk that list 64 candidates at a time: a lane finds the splat that
+// owns its candidate by a binary search over the wave's candidate offsets (shuffles), derives the tile from the
+// candidate's rank inside the rectangle and tests it -
+//    * exact: the ellipse |vPosition| <= 2 really reaches the tile (tile_touches), not just its bounding box;
+//    * skip:  the tile is not yet opaque (`sat`, written by the blend kernel of the previous depth phase) -
+// and one ballot turns the 64 verdicts into a mask from which every splat counts its kept tiles (COUNT) or every kept
+// candidate derives its slot in the pair arrays (EMIT: splat's offset + kept candidates of the same splat before it).
+// No lane ever loops over a rectangle on its own: a splat covering 4000 tiles costs the wave 63 rounds, not one lane
+// 4000, which is what made the exact test a net loss when every thread walked its own rectangle.
+// COUNT and EMIT run the same tests on the same data (sat is not written in between), so the slots are exact.
+template <bool EMIT>
+__global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, const uint32_t* __restrict__ by_depth,
+                                                   const uint32_t* __restrict__ tile_rect, const float4* __restrict__ rec0,
+                                                   const float4* __restrict__ rec1, float H, int tiles_x, int exact,
+                                                   const uint8_t* __restrict__ sat, uint32_t* __restrict__ count_out,
+                                                   const uint32_t* __restrict__ offset, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, const unsigned long long* __restrict__ total_dev,
+                                                   unsigned long long cap) {
+    if (EMIT && *total_dev > cap) return;  // the phase does not fit the pair buffers: the host redoes the frame with larger ones
+    const long long j = j0 + (long long)blockIdx.x * kRB + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const bool live = j < n;
-    const uint32_t cnt = live ? count_sorted[j] : 0u;
-    if (exact_cull) {
-        // culled binning keeps the per-splat loop: the kept tiles are not a dense rectangle
-        if (cnt == 0) return;
-        const uint32_t i = by_depth[j];
-        const uint32_t rect = tile_rect[i];
-        const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
-        uint32_t o = offset[j];
-        const uint32_t o_end = o + cnt;  // never write past this splat's share
-        const bool cull = tx1 > tx0 || ty1 > ty0;  // must mirror preprocess_kernel's count exactly
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        if (cull) {
-            r0 = rec0[i];
-            r1 = rec1[i];
-        }
-        for (uint32_t ty = ty0; ty <= ty1; ++ty)
-            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                if (cull && !tile_touches(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, H, tx, ty)) continue;
-                if (o >= o_end) return;
-                keys[o] = ty * (uint32_t)tiles_x + tx;
-                vals[o] = i;
-                ++o;
-            }
+    const bool live = j < j1;
+    const uint32_t i = live ? by_depth[j] : 0u;
+    const uint32_t rect = live ? tile_rect[i] : kEmptyRect;
+    const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
+    const uint32_t w = tx1 >= tx0 ? tx1 - tx0 + 1u : 0u;
+    const uint32_t area = w * (ty1 >= ty0 ? ty1 - ty0 + 1u : 0u);
+    // candidate offsets inside the wave: exclusive scan of the areas
+    uint32_t inc = area;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    const uint32_t total = __shfl(inc, 63);
+    if (total == 0) {  // wave-uniform
+        if (!EMIT && live) count_out[j - j0] = 0u;
         return;
     }
-    const uint32_t off = live ? offset[j] : 0u;
-    const uint32_t i = (live && cnt) ? by_depth[j] : 0u;
-    const uint32_t rect = (live && cnt) ? tile_rect[i] : 0u;
-    // wave totals: first offset and number of pairs of the wave's stretch
-    uint32_t total = cnt;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-    if (total == 0) return;
-    // start of the stretch = offset of the first live lane (offsets are non-decreasing with the lane)
-    const uint32_t start = __shfl(off, 0);
-    // the search key: offsets are non-decreasing over the lanes; a splat without tiles shares its offset with the
-    // next splat that has some, and that one is the LAST lane holding the value; lanes past n carry the end
-    const uint32_t my_off = live ? off : start + total;
-    // every lane runs every iteration: the shuffles below read registers of ALL lanes (a lane that had left the
-    // loop would hand out zeros); only the stores are predicated
+    const uint32_t cstart = inc - area;
+    if (!EMIT && !exact && !sat) {  // wave-uniform: nothing to test, every tile of the rectangle is kept
+        if (live) count_out[j - j0] = area;
+        return;
+    }
+    const bool test = exact && area > 1u;  // a one-tile rectangle holds the centre's tile or touches it by construction
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+    if (test) {
+        r0 = rec0[i];
+        r1 = rec1[i];
+    }
+    const uint32_t my_off = EMIT && live ? offset[j - j0] : 0u;
+    uint32_t kept_run = 0;  // kept candidates of MY splat in the rounds so far
+    // every lane runs every round: the shuffles read registers of ALL lanes; only the stores are predicated
     for (uint32_t base = 0; base < total; base += 64u) {
         const uint32_t e = base + (uint32_t)lane;
-        const uint32_t target = start + min(e, total - 1u);
-        int lo = 0, hi = 63;  // largest lane s with my_off[s] <= target
+        const bool valid = e < total;
+        const uint32_t target = valid ? e : total - 1u;
+        int lo = 0, hi = 63;  // the LAST lane whose candidates start at or before `target` (empty splats share their
+                              // start with the next non-empty one, which is the later lane)
 #pragma unroll
         for (int step = 0; step < 6; ++step) {
             const int mid = (lo + hi + 1) >> 1;
-            const uint32_t om = __shfl(my_off, mid);
+            const uint32_t om = __shfl(cstart, mid);
             if (om <= target) lo = mid;
             else hi = mid - 1;
         }
-        const uint32_t s_off = __shfl(my_off, lo);
+        const uint32_t s_start = __shfl(cstart, lo);
         const uint32_t s_rect = __shfl(rect, lo);
-        const uint32_t s_i = __shfl(i, lo);
-        const uint32_t tx0 = s_rect & 255u, tx1 = (s_rect >> 8) & 255u, ty0 = (s_rect >> 16) & 255u;
-        const uint32_t w = tx1 - tx0 + 1u;
-        const uint32_t local = target - s_off;
-        const uint32_t ry = local / w, rx = local - ry * w;
-        if (e < total) {
-            keys[target] = (ty0 + ry) * (uint32_t)tiles_x + (tx0 + rx);
-            vals[target] = s_i;
+        const uint32_t s_tx0 = s_rect & 255u, s_tx1 = (s_rect >> 8) & 255u, s_ty0 = (s_rect >> 16) & 255u;
+        const uint32_t s_w = s_tx1 - s_tx0 + 1u;
+        const uint32_t local = target - s_start;
+        const uint32_t ry = local / s_w, rx = local - ry * s_w;
+        const uint32_t tx = s_tx0 + rx, ty = s_ty0 + ry;
+        const uint32_t tile = ty * (uint32_t)tiles_x + tx;
+        bool keep = valid;
+        if (exact) {  // wave-uniform
+            const int s_test = __shfl((int)test, lo);
+            const float a0 = __shfl(r0.x, lo), a1 = __shfl(r0.y, lo), a2 = __shfl(r0.z, lo), a3 = __shfl(r0.w, lo);
+            const float b0 = __shfl(r1.x, lo), b1 = __shfl(r1.y, lo);
+            if (keep && s_test) keep = tile_touches(a0, a1, a2, a3, b0, b1, H, tx, ty);
         }
+        if (sat && keep) keep = sat[tile] == 0;
+        if (EMIT && !exact && !sat) {  // wave-uniform fast path: slot = the splat's offset + the candidate's rank in its rectangle
+            const uint32_t pos = __shfl(my_off, lo) + local;  // shuffles outside the predicate: every lane must take part
+            const uint32_t s_i = __shfl(i, lo);
+            if (keep) {
+                keys[pos] = tile;
+                vals[pos] = s_i;
+            }
+            continue;
+        }
+        const unsigned long long verdict = __ballot(keep);
+        // bits of this round that belong to my splat: candidates [cstart, cstart + area) shifted by base
+        const long long mlo = (long long)cstart - (long long)base, mhi = mlo + (long long)area;
+        const int blo = (int)(mlo < 0 ? 0 : (mlo > 64 ? 64 : mlo)), bhi = (int)(mhi < 0 ? 0 : (mhi > 64 ? 64 : mhi));
+        const unsigned long long below_hi = bhi >= 64 ? ~0ull : ((1ull << bhi) - 1ull);
+        const unsigned long long below_lo = blo >= 64 ? ~0ull : ((1ull << blo) - 1ull);
+        const uint32_t mine = (uint32_t)__popcll(verdict & below_hi & ~below_lo);
+        if (EMIT) {
+            const uint32_t s_prior = __shfl(kept_run, lo);   // kept candidates of the owner in earlier rounds
+            const uint32_t s_off = __shfl(my_off, lo);
+            const uint32_t s_i = __shfl(i, lo);
+            const long long slo = (long long)s_start - (long long)base;
+            const int sblo = (int)(slo < 0 ? 0 : slo);        // first bit of the owner in this round (<= lane)
+            const unsigned long long upto = (1ull << lane) - 1ull;
+            const unsigned long long from = sblo >= 64 ? ~0ull : ((1ull << sblo) - 1ull);
+            const uint32_t rank = s_prior + (uint32_t)__popcll(verdict & upto & ~from);
+            if (keep) {
+                keys[s_off + rank] = tile;
+                vals[s_off + rank] = s_i;
+            }
+        }
+        kept_run += mine;
     }
+    if (!EMIT && live) count_out[j - j0] = kept_run;
 }
 
-__global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, long long P, int ntiles,
-                                                      int2* __restrict__ ranges) {
+__global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ total,
+                                                      unsigned long long cap, int ntiles, int2* __restrict__ ranges) {
+    const unsigned long long tot = *total;
+    const long long P = tot > cap ? 0 : (long long)tot;
     const long long p = (long long)blockIdx.x * kRB + threadIdx.x;
     if (p >= P) return;
     const uint32_t t = keys[p];
@@ -583,15 +618,14 @@ __global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict_
 // ---- host drivers -----------------------------------------------------------------------------------------
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kRB - 1) / kRB); }
 
-static int exclusive_scan_u32(Ctx* c, const uint32_t* in, uint32_t* out, long long n, uint32_t* grand_dev) {
+static int exclusive_scan_u32(Ctx* c, const uint32_t* in, uint32_t* out, long long n, unsigned long long* grand_dev) {
     const int m = (int)((n + kScanTile - 1) / kScanTile);
     GSX_HIP(c, c->r_scan.ensure(sizeof(uint32_t) * (size_t)(m + 1)));
     uint32_t* sums = c->r_scan.as<uint32_t>();
     {
         ProfScope ps(c, "scan");
         hipLaunchKernelGGL(scan_sums_kernel, dim3(m), dim3(kRB), 0, c->stream, in, n, sums);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kRB), 0, c->stream, sums, m, grand_dev);
-        hipLaunchKernelGGL(scan_down_kernel, dim3(m), dim3(kRB), 0, c->stream, in, n, sums, out);
+        hipLaunchKernelGGL(scan_down_kernel, dim3(m), dim3(kRB), 0, c->stream, in, n, sums, out, grand_dev);
     }
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
@@ -650,7 +684,6 @@ int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const
     GSX_HIP(c, hipGetLastError());
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     c->rn = n;
-    c->r_sh_valid = false;
     c->r_sh_on = false;
     return GSX_OK;
 }
@@ -699,7 +732,6 @@ int upload_sh(Ctx* c, const float* f_rest, int deg) {
         GSX_HIP(c, hipMemcpyAsync(drest.p, f_rest, sizeof(float) * 3 * (size_t)(K - 1) * n, hipMemcpyHostToDevice, c->stream));
     }
     GSX_HIP(c, c->r_shc.ensure(sizeof(float) * 3 * (size_t)K * n));
-    GSX_HIP(c, c->r_sh.ensure(sizeof(float) * 3 * (size_t)n));
     hipLaunchKernelGGL(sh_pack_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_order.as<uint32_t>(), n,
                        c->r_fdc.as<float>(), K > 1 ? drest.as<float>() : nullptr, K, c->r_shc.as<float>());
     GSX_HIP(c, hipGetLastError());
@@ -709,9 +741,21 @@ int upload_sh(Ctx* c, const float* f_rest, int deg) {
     return GSX_OK;
 }
 
-int launch_blend(Ctx* c, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
-                 unsigned long long* consumed_dev);  // blend.hip
+int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
+                 unsigned long long* consumed_dev, uint8_t* sat, int first_phase, int last_phase);  // blend.hip
 
+// One frame.  Per view: pre_kernel (depth keys, vertex shader, colours, tile rectangles), bucket_kernel, the level-1
+// sort of the splats by depth bucket; then the splats are rasterized FRONT TO BACK IN DEPTH PHASES (the nearest
+// n/r^(K-1) splats, the next ones up to n/r^(K-2), .., the rest): each phase bins its splats into the tiles that are not
+// opaque yet (bin_kernel COUNT -> scan -> EMIT), sorts its (tile, splat) pairs by tile, and blends them on top of the
+// image, marking the tiles whose every pixel has reached 1 - alpha < 1e-5.  A dense scene sorts a few times the pairs
+// the blend really consumes instead of all of them (3 M splats at 1080p: 22 M pairs bounded by the boxes, 2.2 M
+// consumed); what is skipped could not have changed any channel by more than 1e-5 (the remaining transmittance bounds
+// the sum of everything behind it).
+// The host never waits inside a frame: the pair count of a phase stays on the device, the sort / ranges kernels are
+// launched for the CAPACITY of the pair buffers and read the count themselves.  Only the end-of-frame read-back tells
+// the host whether a phase overflowed the buffers; then they are enlarged and the frame is redone (first frame of a
+// scene, or a much closer view).
 int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, hipSetDevice(c->device));
     if (!cam || W < 1 || H < 1) return fail(c, GSX_E_INVALID, "render_view: bad arguments");
@@ -724,120 +768,167 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     c->r_W = W;
     c->r_H = H;
     const int ntiles = tiles_x * tiles_y;
+    constexpr int kMaxPhases = 8;
     GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)ntiles));
-    GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)ntiles, c->stream));
-    GSX_HIP(c, c->r_small.ensure(64));
-    int* minmax = c->r_small.as<int>();        // [0]=min [1]=max [2]=dropped [3]=P [4..5]=pairs consumed by blend (u64)
-    const int init[6] = {2147483647, -2147483647 - 1, 0, 0, 0, 0};
-    GSX_HIP(c, hipMemcpyAsync(minmax, init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, c->r_sat.ensure((size_t)ntiles));
+    GSX_HIP(c, c->r_small.ensure(256));
+    // [0]=min [1]=max [2]=dropped [3]=pad, then u64: [2]=pairs consumed, [3 + p]=pairs of phase p
+    int* small = c->r_small.as<int>();
+    unsigned long long* small64 = reinterpret_cast<unsigned long long*>(small);
+    unsigned long long* consumed_dev = small64 + 2;
+    unsigned long long* pairs_dev = small64 + 3;
     c->r_P = 0;
-    if (n > 0) {
-        ViewUniforms u{};
-        double view[16], proj[16], vp[16];
-        js_view_matrix(cam, view);
-        js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
-        js_multiply4(proj, view, vp);
-        u.vp2 = vp[2];
-        u.vp6 = vp[6];
-        u.vp10 = vp[10];
-        for (int k = 0; k < 16; ++k) {  // gl.uniformMatrix4fv: JS numbers -> f32
-            u.view[k] = (float)view[k];
-            u.proj[k] = (float)proj[k];
-        }
-        u.fx = (float)cam->fx;
-        u.fy = (float)cam->fy;
-        u.W = (float)W;
-        u.H = (float)H;
-        u.tiles_x = tiles_x;
-        u.tiles_y = tiles_y;
-        const size_t n4 = 4 * (size_t)n;
-        GSX_HIP(c, c->r_depth.ensure(n4));
-        GSX_HIP(c, c->r_bucket.ensure(n4));
-        GSX_HIP(c, c->r_rect.ensure(n4));
-        GSX_HIP(c, c->r_count.ensure(n4));
-        GSX_HIP(c, c->r_offset.ensure(n4));
-        GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
-        GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
-        GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
-        c->r_sh_valid = false;
-        if (c->r_sh_on) {
-            ProfScope ps(c, "render_sh");
-            hipLaunchKernelGGL(sh_color_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n,
-                               c->r_shc.as<float>(), c->r_sh_deg, (float)cam->p[0], (float)cam->p[1], (float)cam->p[2],
-                               c->r_sh.as<float>());
-            c->r_sh_valid = true;
+    c->r_consumed = 0;
+    if (n <= 0) {  // no splats at all: the cleared canvas
+        GSX_HIP(c, hipMemsetAsync(c->r_image.p, 0, img_bytes, c->stream));
+        if (rgba_out) GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        return GSX_OK;
+    }
+    ViewUniforms u{};
+    double view[16], proj[16], vp[16];
+    js_view_matrix(cam, view);
+    js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
+    js_multiply4(proj, view, vp);
+    u.vp2 = vp[2];
+    u.vp6 = vp[6];
+    u.vp10 = vp[10];
+    for (int k = 0; k < 16; ++k) {  // gl.uniformMatrix4fv: JS numbers -> f32
+        u.view[k] = (float)view[k];
+        u.proj[k] = (float)proj[k];
+    }
+    u.fx = (float)cam->fx;
+    u.fy = (float)cam->fy;
+    u.W = (float)W;
+    u.H = (float)H;
+    u.tiles_x = tiles_x;
+    u.tiles_y = tiles_y;
+    const size_t n4 = 4 * (size_t)n;
+    GSX_HIP(c, c->r_depth.ensure(n4));
+    GSX_HIP(c, c->r_bucket.ensure(n4));
+    GSX_HIP(c, c->r_rect.ensure(n4));
+    GSX_HIP(c, c->r_count.ensure(n4));
+    GSX_HIP(c, c->r_offset.ensure(n4));
+    GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
+    GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
+    GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
+    GSX_HIP(c, c->r_d0.ensure(n4));
+    GSX_HIP(c, c->r_d1.ensure(n4));
+    GSX_HIP(c, c->r_d2.ensure(n4));
+    GSX_HIP(c, c->r_d3.ensure(n4));
+    // depth phases: boundaries n / r^(K-1), n / r^(K-2), .., n / r, n
+    const int K = std::max(1, std::min(c->opt_render_phases, kMaxPhases));
+    const long long ratio = std::max(2, std::min(c->opt_render_phase_ratio, 64));
+    long long bounds[kMaxPhases + 1];
+    bounds[0] = 0;
+    for (int p = 1; p <= K; ++p) {
+        long long div = 1;
+        for (int q = p; q < K; ++q) div *= ratio;
+        bounds[p] = std::max(bounds[p - 1], n / div);
+    }
+    bounds[K] = n;
+    int tile_bits = 1;
+    while ((1 << tile_bits) < ntiles) ++tile_bits;
+    if (c->r_pair_cap == 0) c->r_pair_cap = std::max<size_t>((size_t)1 << 20, 2 * (size_t)n);
+
+    for (int attempt = 0;; ++attempt) {
+        const size_t cap = c->r_pair_cap;
+        GSX_HIP(c, c->r_keys0.ensure(4 * cap));
+        GSX_HIP(c, c->r_keys1.ensure(4 * cap));
+        GSX_HIP(c, c->r_vals0.ensure(4 * cap));
+        GSX_HIP(c, c->r_vals1.ensure(4 * cap));
+        GSX_HIP(c, hipMemsetAsync(c->r_sat.p, 0, (size_t)ntiles, c->stream));
+        static const int kInit[64] = {2147483647, -2147483647 - 1};  // depth min / max; counters 0 (static: outlives the copy)
+        GSX_HIP(c, hipMemcpyAsync(small, kInit, sizeof kInit, hipMemcpyHostToDevice, c->stream));
+        {
+            ProfScope ps(c, "render_pre");
+            hipLaunchKernelGGL(pre_kernel, dim3(std::min<unsigned>(grid_for(n), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
+                               c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, (float)cam->p[0], (float)cam->p[1],
+                               (float)cam->p[2], c->r_depth.as<int>(), small, c->r_rec0.as<float4>(), c->r_rec1.as<float4>(),
+                               c->r_rec2.as<float2>(), c->r_rect.as<uint32_t>());
         }
         {
-            ProfScope ps(c, "render_depth");
-            hipLaunchKernelGGL(depth_kernel, dim3(std::min<unsigned>(grid_for(n), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
-                               c->r_depth.as<int>(), minmax);
-        }
-        {
-            ProfScope ps(c, "render_preprocess");
-            hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
-                               c->r_depth.as<int>(), minmax, c->r_sh_valid ? c->r_sh.as<float>() : nullptr,
-                               c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), c->r_bucket.as<uint32_t>(),
-                               c->r_rect.as<uint32_t>(), c->r_count.as<uint32_t>(), minmax + 2, c->opt_exact_cull);
+            ProfScope ps(c, "render_bucket");
+            hipLaunchKernelGGL(bucket_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_depth.as<int>(), n, small,
+                               c->r_bucket.as<uint32_t>(), c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_rect.as<uint32_t>(),
+                               small + 2);
         }
         GSX_HIP(c, hipGetLastError());
         // level 1: splats by depth bucket (stable)
-        GSX_HIP(c, c->r_d0.ensure(n4));
-        GSX_HIP(c, c->r_d1.ensure(n4));
-        GSX_HIP(c, c->r_d2.ensure(n4));
-        GSX_HIP(c, c->r_d3.ensure(n4));
-        GSX_HIP(c, hipMemcpyAsync(c->r_d0.p, c->r_bucket.p, n4, hipMemcpyDeviceToDevice, c->stream));
-        hipLaunchKernelGGL(iota2_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_d1.as<uint32_t>(), n);
         int dwhere = 0;
         int rc = radix_sort_pairs(c, c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_d2.as<uint32_t>(), c->r_d3.as<uint32_t>(),
-                                  n, 17, &dwhere);
+                                  n, 16, &dwhere);
         if (rc) return rc;
         const uint32_t* by_depth = dwhere ? c->r_d3.as<uint32_t>() : c->r_d1.as<uint32_t>();
-        uint32_t* count_sorted = dwhere ? c->r_d0.as<uint32_t>() : c->r_d2.as<uint32_t>();  // the free key buffer
-        hipLaunchKernelGGL(gather_count_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, by_depth, n,
-                           c->r_count.as<uint32_t>(), count_sorted);
-        GSX_HIP(c, hipGetLastError());
-        rc = exclusive_scan_u32(c, count_sorted, c->r_offset.as<uint32_t>(), n, (uint32_t*)(minmax + 3));
-        if (rc) return rc;
-        uint32_t P = 0;
-        GSX_HIP(c, hipMemcpyAsync(&P, minmax + 3, 4, hipMemcpyDeviceToHost, c->stream));
-        GSX_HIP(c, hipStreamSynchronize(c->stream));
-        c->r_P = P;
-        if (P > 0) {
-            GSX_HIP(c, c->r_keys0.ensure(4 * (size_t)P));
-            GSX_HIP(c, c->r_keys1.ensure(4 * (size_t)P));
-            GSX_HIP(c, c->r_vals0.ensure(4 * (size_t)P));
-            GSX_HIP(c, c->r_vals1.ensure(4 * (size_t)P));
-            {
-                ProfScope ps(c, "render_emit");
-                hipLaunchKernelGGL(emit_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, n, by_depth, c->r_rect.as<uint32_t>(),
-                                   count_sorted, c->r_offset.as<uint32_t>(), tiles_x, c->r_rec0.as<float4>(),
-                                   c->r_rec1.as<float4>(), (float)H, c->opt_exact_cull, c->r_keys0.as<uint32_t>(),
-                                   c->r_vals0.as<uint32_t>());
-            }
-            GSX_HIP(c, hipGetLastError());
-            int tile_bits = 1;
-            while ((1 << tile_bits) < ntiles) ++tile_bits;
+        int first_phase = 1;
+        for (int p = 0; p < K; ++p) {
+            const long long j0 = bounds[p], j1 = bounds[p + 1], m = j1 - j0;
+            const bool last = p == K - 1;
+            if (m <= 0 && !last) continue;
+            const uint8_t* sat = first_phase ? nullptr : c->r_sat.as<uint8_t>();
             int where = 0;
-            rc = radix_sort_pairs(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
-                                  c->r_vals1.as<uint32_t>(), P, tile_bits, &where);
-            if (rc) return rc;
-            c->r_sorted_in = where;
-            {
-                ProfScope ps(c, "render_ranges");
-                hipLaunchKernelGGL(ranges_kernel, dim3(grid_for(P)), dim3(kRB), 0, c->stream,
-                                   where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), (long long)P, ntiles,
-                                   c->r_ranges.as<int2>());
+            if (m > 0) {
+                {
+                    ProfScope ps(c, "render_bin_count");
+                    hipLaunchKernelGGL(bin_kernel<false>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
+                                       c->r_rect.as<uint32_t>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), (float)H, tiles_x,
+                                       c->opt_exact_cull, sat, c->r_count.as<uint32_t>(), (const uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
+                }
+                GSX_HIP(c, hipGetLastError());
+                rc = exclusive_scan_u32(c, c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), m, pairs_dev + p);
+                if (rc) return rc;
+                {
+                    ProfScope ps(c, "render_bin_emit");
+                    hipLaunchKernelGGL(bin_kernel<true>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
+                                       c->r_rect.as<uint32_t>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), (float)H, tiles_x,
+                                       c->opt_exact_cull, sat, (uint32_t*)nullptr, c->r_offset.as<uint32_t>(),
+                                       c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap);
+                }
+                GSX_HIP(c, hipGetLastError());
+                rc = radix_sort_pairs_dev(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
+                                          c->r_vals1.as<uint32_t>(), (long long)cap, pairs_dev + p, tile_bits, &where);
+                if (rc) return rc;
             }
-            GSX_HIP(c, hipGetLastError());
+            GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)ntiles, c->stream));
+            if (m > 0) {
+                ProfScope ps(c, "render_ranges");
+                hipLaunchKernelGGL(ranges_kernel, dim3(grid_for((long long)cap)), dim3(kRB), 0, c->stream,
+                                   where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap,
+                                   ntiles, c->r_ranges.as<int2>());
+                GSX_HIP(c, hipGetLastError());
+            }
+            c->r_sorted_in = where;
+            rc = launch_blend(c, where ? c->r_vals1.as<uint32_t>() : c->r_vals0.as<uint32_t>(), W, H, tiles_x, tiles_y, small + 2,
+                              consumed_dev, c->r_sat.as<uint8_t>(), first_phase, last ? 1 : 0);
+            if (rc) return rc;
+            first_phase = 0;
         }
+        // end of frame: the only host wait.  Did every phase fit the pair buffers?
+        unsigned long long stats[3 + kMaxPhases];
+        GSX_HIP(c, hipMemcpyAsync(stats, small, sizeof stats, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+        unsigned long long maxP = 0, sumP = 0;
+        for (int p = 0; p < K; ++p) {
+            maxP = std::max(maxP, stats[3 + p]);
+            sumP += stats[3 + p];
+        }
+        if (maxP > 0x7fffffffull)  // offsets are 32 bit (and the scan's partial sums would have wrapped beyond 2^32)
+            return fail(c, GSX_E_RANGE, "render_view: %llu (tile, splat) pairs in one depth phase exceed 2^31-1 "
+                                        "(a close-up of a very large scene): raise the option \"render_phases\"", maxP);
+        if (maxP > cap) {
+            if (attempt >= 2) return fail(c, GSX_E_STATE, "render_view: pair buffers overflowed three times in a row");
+            c->r_pair_cap = (size_t)(maxP + maxP / 4 + 4096);
+            continue;
+        }
+        c->r_P = sumP;
+        c->r_consumed = stats[2];
+        break;
     }
-    int rc = launch_blend(c, W, H, tiles_x, tiles_y, minmax + 2, reinterpret_cast<unsigned long long*>(minmax + 4));
-    if (rc) return rc;
-    unsigned long long consumed = 0;
-    GSX_HIP(c, hipMemcpyAsync(&consumed, minmax + 4, 8, hipMemcpyDeviceToHost, c->stream));
-    if (rgba_out) GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
-    GSX_HIP(c, hipStreamSynchronize(c->stream));
-    c->r_consumed = consumed;
+    if (rgba_out) {
+        GSX_HIP(c, hipMemcpyAsync(rgba_out, c->r_image.p, img_bytes, hipMemcpyDeviceToHost, c->stream));
+        GSX_HIP(c, hipStreamSynchronize(c->stream));
+    }
     return GSX_OK;
 }
 

@@ -30,10 +30,21 @@ static constexpr int kSortItems = 16;                          // keys per threa
 static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per workgroup (8192 measured 18 % slower)
 static constexpr int kWaveChunk = 64 * kSortItems;             // 1024 consecutive keys per wave
 
+// Element counts may live on the device (n_dev != nullptr: the rasterizer's pair count of the current depth phase, which
+// the host never waits for): the launch is then sized for the CAPACITY n, workgroups past the actual count leave at
+// once, and `ntiles` is only the row pitch of the histogram table.
+__device__ __forceinline__ long long actual_count(long long n, const unsigned long long* __restrict__ n_dev) {
+    if (!n_dev) return n;
+    const unsigned long long v = *n_dev;
+    return v > (unsigned long long)n ? 0 : (long long)v;  // over capacity: the caller redoes the frame with larger buffers
+}
+
 __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long n,
-                                                                 int shift, uint32_t mask,
-                                                                 uint32_t* __restrict__ hist, int ntiles) {
+                                                                 const unsigned long long* __restrict__ n_dev, int shift,
+                                                                 uint32_t mask, uint32_t* __restrict__ hist, int ntiles) {
     __shared__ uint32_t h[256];
+    n = actual_count(n, n_dev);
+    if ((long long)blockIdx.x * kSortTile >= n) return;
     h[threadIdx.x] = 0;
     __syncthreads();
     const long long base = (long long)blockIdx.x * kSortTile;
@@ -47,11 +58,13 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* 
 }
 
 // block d: exclusive scan of hist[d][0..ntiles) in place; rowsum[d] = total
-__global__ __launch_bounds__(kSortBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, int ntiles,
+__global__ __launch_bounds__(kSortBlock) void radix_rowscan_kernel(uint32_t* __restrict__ hist, int ntiles, long long n,
+                                                                    const unsigned long long* __restrict__ n_dev,
                                                                     uint32_t* __restrict__ rowsum) {
     __shared__ uint32_t wsum[kSortWaves];
     __shared__ uint32_t carry_s;
     uint32_t* row = hist + (long long)blockIdx.x * ntiles;
+    ntiles = (int)((actual_count(n, n_dev) + kSortTile - 1) / kSortTile);  // tiles in use; the pitch stays the launch's
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -80,8 +93,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out, long long n,
-                                                                    int shift, uint32_t mask,
-                                                                    const uint32_t* __restrict__ hist,
+                                                                    const unsigned long long* __restrict__ n_dev, int shift,
+                                                                    uint32_t mask, const uint32_t* __restrict__ hist,
                                                                     const uint32_t* __restrict__ rowsum, int ntiles) {
     __shared__ uint32_t gbase[256];               // global start of this tile's run of each digit
     __shared__ uint32_t dstart[256];              // start of each digit inside the tile's locally sorted order
@@ -91,6 +104,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     __shared__ uint32_t sv[kSortTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int d = threadIdx.x;
+    n = actual_count(n, n_dev);
+    if ((long long)blockIdx.x * kSortTile >= n) return;  // workgroup-uniform
 
     // digit bases: exclusive scan of rowsum over the 256 digits + this tile's offset inside the digit
     {
@@ -187,8 +202,14 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
 // Sorts n pairs by key bits [0, bits).  Ping-pongs between (k0,v0) and (k1,v1); *result_in is 0 or 1.
 int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n, int bits,
                      int* result_in) {
+    return radix_sort_pairs_dev(c, k0, v0, k1, v1, n, nullptr, bits, result_in);
+}
+
+// n: element count, or the buffers' capacity when the count is read from n_dev on the device (see actual_count).
+int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
+                         const unsigned long long* n_dev, int bits, int* result_in) {
     *result_in = 0;
-    if (n <= 1 || bits <= 0) return GSX_OK;
+    if ((n <= 1 && !n_dev) || n <= 0 || bits <= 0) return GSX_OK;
     const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
     GSX_HIP(c, c->sort_hist.ensure(sizeof(uint32_t) * ((size_t)256 * ntiles + 256)));
     uint32_t* hist = c->sort_hist.as<uint32_t>();
@@ -204,16 +225,16 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
         const uint32_t mask = (1u << width) - 1u;  // key bits >= `bits` never take part
         {
             ProfScope ps(c, "radix_hist");
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, shift, mask, hist, ntiles);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, n_dev, shift, mask, hist, ntiles);
         }
         {
             ProfScope ps(c, "radix_rowscan");
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(kSortBlock), 0, c->stream, hist, ntiles, rowsum);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(kSortBlock), 0, c->stream, hist, ntiles, n, n_dev, rowsum);
         }
         {
             ProfScope ps(c, "radix_scatter");
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, shift,
-                               mask, hist, rowsum, ntiles);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, n_dev,
+                               shift, mask, hist, rowsum, ntiles);
         }
         GSX_HIP(c, hipGetLastError());
         std::swap(ki, ko);

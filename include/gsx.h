@@ -94,10 +94,16 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               instructions per visible pair, yet both axes are evaluated before the first early-out
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
  *   "blend_pk2"    (default 1)  rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four (one wave per tile)
+ *   "render_phases" (default 2) rasterizer: a frame is binned, sorted and blended front to back in this many DEPTH
+ *                               PHASES (1..8); a phase skips the tiles the earlier ones left opaque (1 - alpha <
+ *                               1e-5 on every pixel), so a dense scene sorts a few times the (tile, splat) pairs the
+ *                               blend consumes instead of all of them (3 M splats @1080p: 23.3 M pairs -> 7.2 M with 2
+ *                               phases, 2.2 M consumed).  What is skipped could not have moved a channel by 1e-5
+ *   "render_phase_ratio" (default 4)  phase p ends after n / ratio^(K-1-p) splats of the depth order (2..64)
  *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
- *                               (minimum of the quadratic over the tile), not its whole bounding box.  Measured
- *                               on the 3 M-splat scene: pairs -23 %, sort -0.2 ms, but the per-splat tile loops
- *                               diverge (+0.5 ms): off until the binning is wave-cooperative
+ *                               (minimum of the quadratic over the tile), not its whole bounding box.  The binning
+ *                               is wave-cooperative (no lane walks a rectangle on its own), yet on the 3 M-splat
+ *                               scene the test still costs more (+0.18 ms) than the 23 % fewer pairs save (-0.07)
  *   "tile_lpt"     (default 0)  rasterizer: blend the tiles with the longest splat lists first (measured:
  *                               blend -3 %, paid back by the extra ordering launches)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as strips of 16 pixel columns (16x8 pixels per 128-B line;

@@ -126,6 +126,33 @@ def test_render_options_do_not_change_the_frame(gsx):
     assert pairs[1] < 0.8 * pairs[0]
 
 
+def test_depth_phases_do_not_change_the_frame(gsx):
+    """The frame is rasterized front to back in depth phases; tiles that are already opaque are not binned again.  Any
+    number of phases gives the oracle's frame (<= 1e-4), fewer (tile, splat) pairs the more phases there are, and the
+    pair buffers grow on demand (a fresh context starts with a capacity the first frame overflows)."""
+    n, W, H = 60_000, 640, 360
+    xyz = scene.make_positions(n, 23) * np.float32(0.6)
+    a = scene.make_splat_attributes(n, 23, sh_degree=0)
+    a["scale"] += np.float32(np.log(2.5))
+    a["opacity"] += np.float32(2.0)                       # dense and opaque: most tiles saturate early
+    cam = scene.make_cameras(5, W, H, convention="c2w")[3]
+    want = oracle.render_scene(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cam, W, H)
+    assert (want[..., 3] > 0.999).mean() > 0.15
+    pairs = {}
+    for K, ratio, exact in ((1, 4, 0), (2, 4, 0), (3, 2, 1), (4, 3, 0), (8, 2, 1)):
+        with gsx.Context(0) as c:
+            c.set_option("render_phases", K)
+            c.set_option("render_phase_ratio", ratio)
+            c.set_option("exact_cull", exact)
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            got = c.render_view(cam, W, H)
+            assert np.abs(got - want).max() <= TOL, (K, ratio, exact)
+            again = c.render_view(cam, W, H)          # second frame: buffers already sized, same pixels
+            assert np.array_equal(got, again)
+            pairs[(K, exact)] = c.render_num_pairs()
+    assert pairs[(2, 0)] < 0.7 * pairs[(1, 0)] and pairs[(4, 0)] < pairs[(2, 0)]
+
+
 def test_export_splat_file(ctx, g, tmp_path):
     ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
     path = str(tmp_path / "scene.splat")
