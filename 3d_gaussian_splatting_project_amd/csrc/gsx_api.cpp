@@ -1,6 +1,7 @@
 // libgsx.so — C ABI entry points (include/gsx.h): context, scene upload, profiling, dispatch.
 // No exception crosses the boundary; every entry returns a gsx_status.
 #include <cstring>
+#include <exception>
 #include <new>
 
 #include "gsx_ctx.hpp"
@@ -69,6 +70,21 @@ static void prof_drain(Ctx* c) {
         c->event_pool.push_back(e.stop);
     }
     c->prof_events.clear();
+}
+
+// No exception may cross the C boundary: std::bad_alloc from a host-side vector sized by the caller's counts,
+// std::system_error from a worker thread that cannot be started, ... become a status + gsx_last_error text.
+template <class F>
+static int guard(Ctx* c, const char* who, F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(c, GSX_E_INVALID, "%s: out of host memory", who);
+    } catch (const std::exception& e) {
+        return fail(c, GSX_E_INVALID, "%s: %s", who, e.what());
+    } catch (...) {
+        return fail(c, GSX_E_INVALID, "%s: unknown failure", who);
+    }
 }
 
 }  // namespace gsx
@@ -232,16 +248,19 @@ int gsx_upload_positions_strided(gsx_ctx* ctx, int64_t n, const void* base, int6
     CTX_OR_FAIL(ctx);
     if (n < 0 || (n > 0 && !base) || stride_bytes < 4 || off_x < 0 || off_y < 0 || off_z < 0)
         return gsx::fail(c, GSX_E_INVALID, "upload_positions_strided: bad arguments");
-    // AoS -> SoA transpose on the host (rows are 248+ bytes in a 3DGS PLY; only 12 are wanted)
-    std::vector<float> sx((size_t)n), sy((size_t)n), sz((size_t)n);
-    const char* b = static_cast<const char*>(base);
-    for (int64_t i = 0; i < n; ++i) {
-        const char* row = b + i * stride_bytes;
-        std::memcpy(&sx[i], row + off_x, 4);
-        std::memcpy(&sy[i], row + off_y, 4);
-        std::memcpy(&sz[i], row + off_z, 4);
-    }
-    return gsx_upload_positions(ctx, n, sx.data(), sy.data(), sz.data());
+    if (n > (int64_t)1 << 31) return gsx::fail(c, GSX_E_UNSUPPORTED, "upload_positions_strided: n > 2^31");
+    return gsx::guard(c, __func__, [&] {
+        // AoS -> SoA transpose on the host (rows are 248+ bytes in a 3DGS PLY; only 12 are wanted)
+        std::vector<float> sx((size_t)n), sy((size_t)n), sz((size_t)n);
+        const char* b = static_cast<const char*>(base);
+        for (int64_t i = 0; i < n; ++i) {
+            const char* row = b + i * stride_bytes;
+            std::memcpy(&sx[i], row + off_x, 4);
+            std::memcpy(&sy[i], row + off_y, 4);
+            std::memcpy(&sz[i], row + off_z, 4);
+        }
+        return gsx_upload_positions(ctx, n, sx.data(), sy.data(), sz.data());
+    });
 }
 
 int64_t gsx_num_gaussians(const gsx_ctx* ctx) {
@@ -268,29 +287,29 @@ int gsx_project_one(gsx_ctx* ctx, const float pos[3], const gsx_camera* cam, int
 int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y) {
     CTX_OR_FAIL(ctx);
     if (!cam || !x || !y) return gsx::fail(c, GSX_E_INVALID, "project_all: NULL argument");
-    return gsx::project_all(c, cam, c->x.as<float>(), c->y.as<float>(), c->z.as<float>(), c->n, x, y,
-                            c->sorted ? c->perm.as<uint32_t>() : nullptr);
+    return gsx::guard(c, __func__, [&] { return gsx::project_all(c, cam, c->x.as<float>(), c->y.as<float>(), c->z.as<float>(), c->n, x, y,
+                            c->sorted ? c->perm.as<uint32_t>() : nullptr); });
 }
 
 // ---- vote ----------------------------------------------------------------------------------------
 int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t total_views) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_begin(c, n_classes, first_view, total_views);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_begin(c, n_classes, first_view, total_views); });
 }
 int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
                   int32_t seg_h, int32_t img_w, int32_t img_h) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_view(c, cam, seg, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_view(c, cam, seg, seg_dtype, seg_w, seg_h, img_w, img_h); });
 }
 int gsx_vote_view_device(gsx_ctx* ctx, const gsx_camera* cam, const void* seg_dev, int32_t seg_dtype, int32_t seg_w,
                          int32_t seg_h, int32_t img_w, int32_t img_h) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_views_device(c, 1, cam, &seg_dev, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_views_device(c, 1, cam, &seg_dev, seg_dtype, seg_w, seg_h, img_w, img_h); });
 }
 int gsx_vote_views_device(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, const void* const* segs_dev, int32_t seg_dtype,
                           int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_views_device(c, n, cams, segs_dev, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_views_device(c, n, cams, segs_dev, seg_dtype, seg_w, seg_h, img_w, img_h); });
 }
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
@@ -307,7 +326,7 @@ int gsx_vote_rewind(gsx_ctx* ctx) {
 }
 int gsx_vote_finalize(gsx_ctx* ctx, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_finalize(c, labels_out);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_finalize(c, labels_out); });
 }
 void* gsx_vote_labels_device(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -335,7 +354,7 @@ void* gsx_vote_keys_device(gsx_ctx* ctx, int64_t* n_int32_words) {
 }
 int gsx_vote_labels_from_keys(gsx_ctx* ctx, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_labels_from_keys(c, labels_out);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_labels_from_keys(c, labels_out); });
 }
 void* gsx_vote_first_device(gsx_ctx* ctx, int64_t* n_int32_words) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -349,7 +368,7 @@ int64_t gsx_vote_slab_size(const gsx_ctx* ctx) {
 }
 int gsx_vote_slab_reduce(gsx_ctx* ctx, const void* recv_counts_dev, const void* recv_first_dev) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_slab_reduce(c, recv_counts_dev, recv_first_dev);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_slab_reduce(c, recv_counts_dev, recv_first_dev); });
 }
 int gsx_vote_flush_counts(gsx_ctx* ctx) {
     CTX_OR_FAIL(ctx);
@@ -357,7 +376,7 @@ int gsx_vote_flush_counts(gsx_ctx* ctx) {
 }
 int gsx_vote_slab_totals(gsx_ctx* ctx, const void* recv_counts_dev) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_slab_totals(c, recv_counts_dev);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_slab_totals(c, recv_counts_dev); });
 }
 void* gsx_vote_cand_device(gsx_ctx* ctx, int64_t* n_int32_words) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -367,7 +386,7 @@ void* gsx_vote_cand_device(gsx_ctx* ctx, int64_t* n_int32_words) {
 }
 int gsx_vote_tie_codes(gsx_ctx* ctx, const void* cand_all_dev) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_tie_codes(c, cand_all_dev);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_tie_codes(c, cand_all_dev); });
 }
 void* gsx_vote_codes_device(gsx_ctx* ctx, int64_t* n_int32_words) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -377,24 +396,24 @@ void* gsx_vote_codes_device(gsx_ctx* ctx, int64_t* n_int32_words) {
 }
 int gsx_vote_tie_resolve(gsx_ctx* ctx, const void* recv_codes_dev) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_tie_resolve(c, recv_codes_dev);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_tie_resolve(c, recv_codes_dev); });
 }
 int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_labels_from_sorted(c, sorted_labels_dev, labels_out);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_labels_from_sorted(c, sorted_labels_dev, labels_out); });
 }
 int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_export(c, reserve_bytes, blobs_out, pool_dev, pool_bytes);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_export(c, reserve_bytes, blobs_out, pool_dev, pool_bytes); });
 }
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_import(c, n_parts, part_views, part_offsets, blobs, pool_all_dev, pool_all_bytes);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_import(c, n_parts, part_views, part_offsets, blobs, pool_all_dev, pool_all_bytes); });
 }
 int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_slab_labels(c, slab, slabs, slab_size);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_slab_labels(c, slab, slabs, slab_size); });
 }
 int gsx_host_threads(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -402,18 +421,18 @@ int gsx_host_threads(gsx_ctx* ctx) {
 }
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_debug_planes(c, counts_out, first_out);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_debug_planes(c, counts_out, first_out); });
 }
 
 // ---- rasterizer -----------------------------------------------------------------------------------
 int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* scale, const float* rot,
                       const float* opacity, const float* f_dc, const int32_t* labels) {
     CTX_OR_FAIL(ctx);
-    return gsx::upload_splats(c, n, xyz, scale, rot, opacity, f_dc, labels);
+    return gsx::guard(c, __func__, [&] { return gsx::upload_splats(c, n, xyz, scale, rot, opacity, f_dc, labels); });
 }
 int gsx_upload_sh(gsx_ctx* ctx, const float* f_rest, int32_t sh_degree) {
     CTX_OR_FAIL(ctx);
-    return gsx::upload_sh(c, f_rest, sh_degree);
+    return gsx::guard(c, __func__, [&] { return gsx::upload_sh(c, f_rest, sh_degree); });
 }
 int64_t gsx_num_splats(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
@@ -421,7 +440,7 @@ int64_t gsx_num_splats(const gsx_ctx* ctx) {
 }
 int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::render_view(c, cam, width, height, rgba_out);
+    return gsx::guard(c, __func__, [&] { return gsx::render_view(c, cam, width, height, rgba_out); });
 }
 void* gsx_render_image_device(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
@@ -438,26 +457,26 @@ int64_t gsx_render_num_pairs_consumed(const gsx_ctx* ctx) {
 int gsx_hit_test(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, double x, double y,
                  int32_t* label_out, int64_t* index_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::hit_test(c, cam, width, height, x, y, label_out, index_out);
+    return gsx::guard(c, __func__, [&] { return gsx::hit_test(c, cam, width, height, x, y, label_out, index_out); });
 }
 int gsx_render_debug(gsx_ctx* ctx, uint8_t* buffer_out, uint32_t* order_out, uint32_t* texdata_out,
                      uint32_t* bucket_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::render_debug(c, buffer_out, order_out, texdata_out, bucket_out);
+    return gsx::guard(c, __func__, [&] { return gsx::render_debug(c, buffer_out, order_out, texdata_out, bucket_out); });
 }
 
 int gsx_kmeans(gsx_ctx* ctx, int64_t n, const float* points, const float* colors, int32_t k, const int64_t* init_index,
                int32_t max_iter, double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out,
                int32_t* converged_out) {
     CTX_OR_FAIL(ctx);
-    return gsx::kmeans(c, n, points, colors, k, init_index, max_iter, tol, labels_out, centroids_out, iterations_out,
-                       converged_out);
+    return gsx::guard(c, __func__, [&] { return gsx::kmeans(c, n, points, colors, k, init_index, max_iter, tol, labels_out, centroids_out, iterations_out,
+                       converged_out); });
 }
 
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset) {
     CTX_OR_FAIL(ctx);
     if (!wave_views) return gsx::fail(c, GSX_E_INVALID, "vote_culled: NULL argument");
-    return gsx::vote_culled(c, wave_views, reset != 0);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_culled(c, wave_views, reset != 0); });
 }
 
 int gsx_debug_cull_planes(const gsx_camera* cam, double* out) {

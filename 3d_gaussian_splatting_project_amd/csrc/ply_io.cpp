@@ -17,7 +17,10 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -115,11 +118,38 @@ const Prop* find_prop(const gsx_ply* p, const char* name) {
 
 }  // namespace
 
+namespace {
+int ply_open_impl(const char* path, gsx_ply** out);
+int ply_write_impl(const gsx_ply* p, const char* path, const int32_t* labels, int32_t text);
+
+// no exception may cross the C boundary (std::bad_alloc from a vector sized by a hostile header, std::system_error
+// from a thread that cannot be started, ...)
+template <class F>
+int guarded(const char* who, F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return gsx::fail(nullptr, GSX_E_IO, "%s: out of memory", who);
+    } catch (const std::exception& e) {
+        return gsx::fail(nullptr, GSX_E_IO, "%s: %s", who, e.what());
+    } catch (...) {
+        return gsx::fail(nullptr, GSX_E_IO, "%s: unknown failure", who);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int gsx_ply_open(const char* path, gsx_ply** out) {
     if (!path || !out) return gsx::fail(nullptr, GSX_E_INVALID, "ply_open: NULL argument");
     *out = nullptr;
+    return guarded("ply_open", [&] { return ply_open_impl(path, out); });
+}
+
+}  // extern "C"
+
+namespace {
+int ply_open_impl(const char* path, gsx_ply** out) {
     int fd = ::open(path, O_RDONLY);
     if (fd < 0) return gsx::fail(nullptr, GSX_E_IO, "ply_open: cannot open %s: %s", path, std::strerror(errno));
     struct stat st;
@@ -167,7 +197,14 @@ int gsx_ply_open(const char* path, gsx_ply** out) {
             }
         } else if (kw == "element") {
             if (std::string(b) == "vertex") {
-                p->n = std::atoll(c);
+                char* endp = nullptr;
+                errno = 0;
+                const long long cnt = std::strtoll(c, &endp, 10);
+                if (endp == c || *endp != 0 || errno == ERANGE || cnt < 0) {
+                    delete p;
+                    return bail("`element vertex` carries no valid count");
+                }
+                p->n = cnt;
                 in_vertex = true;
                 seen_vertex = true;
             } else {
@@ -197,15 +234,21 @@ int gsx_ply_open(const char* path, gsx_ply** out) {
         delete p;
         return bail("header lacks format / element vertex / properties");
     }
+    // sizes in the divided form: a header may promise any count, n * stride must never be formed before it is known to fit
+    if (p->stride <= 0 || (uint64_t)p->n > (uint64_t)(len - data_off) / (uint64_t)(format == 1 ? p->stride : 1)) {
+        // binary: n rows of `stride` bytes must be there; ascii: every value needs at least one character
+        delete p;
+        return bail("file is shorter than its header promises");
+    }
     if (format == 1) {
-        if (data_off + (size_t)p->n * (size_t)p->stride > len) {
-            delete p;
-            return bail("file is shorter than its header promises");
-        }
         p->map = map;
         p->map_len = len;
         p->rows = static_cast<unsigned char*>(map) + data_off;
     } else {
+        if ((uint64_t)p->n > (uint64_t)PTRDIFF_MAX / (uint64_t)p->stride / 2) {
+            delete p;
+            return bail("vertex count too large");
+        }
         p->owned.resize((size_t)p->n * (size_t)p->stride);
         p->rows = p->owned.data();
         const char* cur = txt + data_off;
@@ -229,6 +272,9 @@ int gsx_ply_open(const char* path, gsx_ply** out) {
     *out = p;
     return GSX_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void gsx_ply_close(gsx_ply* p) {
     if (!p) return;
@@ -256,13 +302,16 @@ int gsx_ply_read_f32(const gsx_ply* p, const char* name, float* out) {
     const unsigned char* base = p->rows + q->offset;
     const int64_t stride = p->stride;
     const int type = q->type;
-    parallel_rows(p->n, [=](int64_t lo, int64_t hi) {
-        if (type == GSX_PLY_FLOAT)
-            for (int64_t i = lo; i < hi; ++i) std::memcpy(out + i, base + i * stride, 4);
-        else
-            for (int64_t i = lo; i < hi; ++i) out[i] = (float)load_as_double(base + i * stride, type);
+    const int64_t n = p->n;
+    return guarded("ply_read_f32", [&] {
+        parallel_rows(n, [=](int64_t lo, int64_t hi) {
+            if (type == GSX_PLY_FLOAT)
+                for (int64_t i = lo; i < hi; ++i) std::memcpy(out + i, base + i * stride, 4);
+            else
+                for (int64_t i = lo; i < hi; ++i) out[i] = (float)load_as_double(base + i * stride, type);
+        });
+        return (int)GSX_OK;
     });
-    return GSX_OK;
 }
 
 int gsx_ply_set_f32(gsx_ply* p, const char* name, const float* in) {
@@ -272,10 +321,13 @@ int gsx_ply_set_f32(gsx_ply* p, const char* name, const float* in) {
     unsigned char* base = p->rows + q->offset;
     const int64_t stride = p->stride;
     const int type = q->type;
-    parallel_rows(p->n, [=](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) store_from_double(base + i * stride, type, (double)in[i]);
+    const int64_t n = p->n;
+    return guarded("ply_set_f32", [&] {
+        parallel_rows(n, [=](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) store_from_double(base + i * stride, type, (double)in[i]);
+        });
+        return (int)GSX_OK;
     });
-    return GSX_OK;
 }
 
 // All vertex properties (+ a trailing `property int label` when labels != NULL), vertex element only.
@@ -283,8 +335,20 @@ int gsx_ply_write(const gsx_ply* p, const char* path, const int32_t* labels, int
     if (!p || !path) return gsx::fail(nullptr, GSX_E_INVALID, "ply_write: NULL argument");
     if (labels && find_prop(p, "label"))
         return gsx::fail(nullptr, GSX_E_INVALID, "ply_write: the vertex element already has a 'label' property");
-    FILE* f = std::fopen(path, "wb");
-    if (!f) return gsx::fail(nullptr, GSX_E_IO, "ply_write: cannot create %s: %s", path, std::strerror(errno));
+    return guarded("ply_write", [&] { return ply_write_impl(p, path, labels, text); });
+}
+
+}  // extern "C"
+
+namespace {
+// The rows may be a private mapping of the very file being written (--output_file == --ply_file works with plyfile,
+// which holds the data in memory): truncating it in place would pull the pages from under the mapping (SIGBUS) and
+// destroy the input.  So the file is always written next to its destination and renamed over it when complete; a
+// failed write leaves the destination untouched.
+int ply_write_impl(const gsx_ply* p, const char* path, const int32_t* labels, int32_t text) {
+    const std::string tmp = std::string(path) + ".gsx-tmp-" + std::to_string((long long)getpid());
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return gsx::fail(nullptr, GSX_E_IO, "ply_write: cannot create %s: %s", tmp.c_str(), std::strerror(errno));
     std::string h = "ply\nformat ";
     h += text ? "ascii 1.0\n" : "binary_little_endian 1.0\n";
     h += "element vertex " + std::to_string(p->n) + "\n";
@@ -339,8 +403,15 @@ int gsx_ply_write(const gsx_ply* p, const char* path, const int32_t* labels, int
         }
     }
     ok = (std::fclose(f) == 0) && ok;
-    if (!ok) return gsx::fail(nullptr, GSX_E_IO, "ply_write: short write to %s", path);
+    if (!ok) {
+        std::remove(tmp.c_str());
+        return gsx::fail(nullptr, GSX_E_IO, "ply_write: short write to %s", tmp.c_str());
+    }
+    if (std::rename(tmp.c_str(), path) != 0) {
+        const int e = errno;
+        std::remove(tmp.c_str());
+        return gsx::fail(nullptr, GSX_E_IO, "ply_write: cannot move the finished file to %s: %s", path, std::strerror(e));
+    }
     return GSX_OK;
 }
-
-}  // extern "C"
+}  // namespace

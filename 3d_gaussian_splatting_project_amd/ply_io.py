@@ -32,6 +32,9 @@ class PlyElement:
         dtype = np.dtype({"names": names, "formats": formats, "offsets": offsets, "itemsize": int(stride)})
         if n > 0:
             raw = (C.c_ubyte * (n * stride)).from_address(lib.gsx_ply_rows(h))
+            # every numpy view derived from .data keeps `raw` alive, and `raw` keeps the PlyData (hence the native
+            # mapping) alive: `x = PlyData.read(p)['vertex']['x']` must not dangle once the PlyData goes out of scope
+            raw._gsx_owner = owner
             self.data = np.frombuffer(raw, dtype=dtype, count=n)
         else:
             self.data = np.zeros(0, dtype=dtype)

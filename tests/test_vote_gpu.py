@@ -711,6 +711,33 @@ def test_full_size_properties(ctx):
     assert (a != -1).mean() > 0.9 and len(np.unique(a)) == 151
 
 
+def test_config1_full_size_vote_and_raster(ctx):
+    """BASELINE configs[1] at its full size: 500 k Gaussians, 16 views @1280x720, forward raster + vote on one GPU.
+    Vote: ALL 500 k labels equal the oracle's (host maps and device maps).  Raster: two of the 16 views against the
+    oracle's frames (<= 1e-4), the others through size-independent properties (finite, premultiplied, alpha <= 1)."""
+    import torch
+    n, V, W, H = 500_000, 16, 1280, 720
+    pos, cams, segs = scene.make_scene(n, V, W, H, config_id=2, convention="w2c")
+    sizes = [(W, H)] * V
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    assert np.array_equal(run_gpu(ctx, pos, cams, segs, sizes).vote_finalize(), want)
+    ctx.vote_begin(150, 0, V)
+    ctx.vote_views_device(cams, torch.from_numpy(np.stack(segs)).cuda())
+    assert np.array_equal(ctx.vote_finalize(), want)
+    assert (want != -1).mean() > 0.5
+    a = scene.make_splat_attributes(n, scene.BASE_SEED + 2, sh_degree=0)
+    rcams = scene.make_cameras(V, W, H, convention="c2w")
+    ctx.upload_splats(pos, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+    for v, cam in enumerate(rcams):
+        got = ctx.render_view(cam, W, H)
+        assert np.isfinite(got).all() and got.min() >= 0.0 and got[..., 3].max() <= 1.0 + 1e-6
+        assert (got[..., :3] <= got[..., 3:4] + 1e-5).all()          # premultiplied colours never exceed alpha
+        if v in (0, 9):
+            ref = oracle.render_scene(pos, a["scale"], a["rot"], a["opacity"], a["f_dc"], cam, W, H)
+            assert np.abs(got - ref).max() <= 1e-4
+            assert (ref[..., 3] > 0.05).mean() > 0.02
+
+
 def test_randomised_small_configurations(gsx):
     """Many small random configurations (sizes, class counts, scales, map dtypes, camera frames that do not
     match the map, missing visibility, options) against the oracle — bit-exact every time."""

@@ -95,12 +95,12 @@ def golden_project(dls):
     cams = [real[0], real[57], real[310]]
     cams += [look_at_camera(rng, f"syn{i}", w, h) for i, (w, h) in
              enumerate([(1280, 720), (1920, 1080), (640, 480), (3840, 2160), (333, 777)])]
-    n = 12000
+    n = 50000                                  # 50 k positions x 8 cameras
     pos = rng.normal(scale=2.5, size=(n, 3))
     # a third of the points are placed in front of the real cameras (x = R^T pc + p  =>  R @ (x-p) = pc approx)
     for k, c in enumerate(cams[:3]):
         R = np.array(c["rotation"]); p = np.array(c["position"])
-        m = 1300
+        m = 5000
         pc = np.stack([rng.uniform(-3, 3, m), rng.uniform(-2, 2, m), rng.uniform(0.05, 9, m)], 1)
         pos[k * m:(k + 1) * m] = (np.linalg.inv(R) @ pc.T).T + p
     pos = pos.astype(np.float32)
@@ -130,7 +130,9 @@ def golden_project(dls):
             if r is not None:
                 xs[v, i], ys[v, i] = r
     print("G1 visible fraction per camera:", (xs >= 0).mean(1).round(3))
-    np.savez_compressed(os.path.join(OUT, "vote_project.npz"), positions=pos, x=xs, y=ys, **cams_to_arrays(cams))
+    assert xs.max() < 32768 and ys.max() < 32768            # int16 keeps the fixture under a megabyte
+    np.savez_compressed(os.path.join(OUT, "vote_project.npz"), positions=pos, x=xs.astype(np.int16), y=ys.astype(np.int16),
+                        **cams_to_arrays(cams))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -175,7 +177,7 @@ def golden_assign(dls):
     # ---- random scenes, V in {1, 3, 8}, 150 classes + (-1) pixels ---------------------------
     for V in (1, 3, 8):
         rng = np.random.default_rng(0xC0FFEE10 + V)
-        n = 6000
+        n = 20000                              # N = 20 k
         w, h = 320, 180
         cams = [look_at_camera(rng, f"v{V}_{i:03d}", w, h) for i in range(V)]
         pos = rng.normal(scale=1.6, size=(n, 3)).astype(np.float32)
@@ -190,7 +192,7 @@ def golden_assign(dls):
 
     # ---- few coarse classes: many exact ties, pins first-inserted-wins (dls.py:303) -----------
     rng = np.random.default_rng(0xC0FFEE20)
-    V, n, w, h = 6, 5000, 200, 120
+    V, n, w, h = 6, 20000, 200, 120
     cams = [look_at_camera(rng, f"tie_{i:03d}", w, h, radius=5.0) for i in range(V)]
     pos = rng.normal(scale=1.0, size=(n, 3)).astype(np.float32)
     segs = [blocky_segmap(rng, h, w, 3, cell=7) for _ in range(V)]          # labels in {-1,0,1,2}
@@ -202,7 +204,7 @@ def golden_assign(dls):
 
     # ---- missing PNG (camera skipped), seg map smaller than image, cam size != image size ----
     rng = np.random.default_rng(0xC0FFEE30)
-    V, n = 5, 5000
+    V, n = 5, 20000
     cams = [look_at_camera(rng, f"mix_{i:03d}", 320, 180) for i in range(V)]
     cams[2]["width"], cams[2]["height"] = 300, 200          # camera intrinsics size != image size
     cams[4]["fx"] = 250                                      # an int focal, as JSON may hold
