@@ -2,6 +2,8 @@
 #include "host_pack.hpp"
 
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include <atomic>
 #include <condition_variable>
@@ -39,11 +41,15 @@ MapLayout map_layout(int w, int h, bool tiled, bool coarse) {
 }
 
 // ---- worker pool ---------------------------------------------------------------------------------------------------
-// Fork-join with NO shared counters on the hot path: thread t runs the contiguous parts [parts*t/T, parts*(t+1)/T) and
-// reports through its own cache line.  (A shared `next part` counter next to the flag the idle workers poll cost
+// Fork-join without a SHARED counter on the hot path: thread t owns the contiguous parts [parts*t/T, parts*(t+1)/T),
+// claims them one by one from a counter on its own cache line, and only when its share is done helps the others
+// (a thread that shares its core, reads remote memory or was descheduled would otherwise hold the whole call up).
+// Every thread reports through its own line.  (One shared `next part` counter next to the flag the idle workers poll cost
 // 0.3 ms per call on a 2-socket EPYC: every fetch_add fought the pollers for the line.)  Placement: see below.
 struct alignas(64) Slot {
     std::atomic<uint64_t> done{0};  // generation this thread has finished
+    std::atomic<int> next{0};       // next unclaimed part of this thread's share
+    int end = 0;                    // one past the share's last part
 };
 
 struct Workers::Impl {
@@ -59,8 +65,15 @@ struct Workers::Impl {
     Slot* slots = nullptr;
 
     void share(int t) {
-        const int lo = (int)((long long)parts * t / nthreads), hi = (int)((long long)parts * (t + 1) / nthreads);
-        for (int p = lo; p < hi; ++p) fn(arg, p);
+        for (int k = 0; k < nthreads; ++k) {  // own share first, then the others' leftovers
+            Slot& s = slots[(t + k) % nthreads];
+            for (;;) {
+                if (s.next.load(std::memory_order_relaxed) >= s.end) break;  // cheap look before touching the line for real
+                const int p = s.next.fetch_add(1, std::memory_order_relaxed);
+                if (p >= s.end) break;
+                fn(arg, p);
+            }
+        }
     }
     void loop(int t) {
         uint64_t seen = 0;
@@ -88,9 +101,10 @@ struct Workers::Impl {
 // Measured on a 2-socket EPYC 9575F (8 CCDs of 8 cores per socket), 16 threads packing 1080p maps:
 //   unpinned 130 GB/s of int32 bytes, all on two CCDs 110 (a CCD's fabric link carries ~55 GB/s), one per CCD across
 //   BOTH sockets 23 (remote memory + the fork-join lines bouncing between sockets), two per CCD on the caller's socket
-//   167.  So: stay on the NUMA node of the thread that creates the pool (the maps it hands over were, as a rule,
-//   written by that thread) and deal the workers round-robin over that node's L3 domains.  Each worker is bound to
-//   the CPUs of one L3 domain, not to one CPU.  GSX_HOST_AFFINITY=0 leaves the threads where the scheduler puts them.
+//   167; maps on the OTHER node than the pool 78.  So: the pool lives on the NUMA node that holds the first map it is
+//   given (move_pages query; else the node of the thread that creates it) and deals its workers round-robin over that
+//   node's L3 domains.  Each worker is bound to the CPUs of one L3 domain, not to one CPU.  GSX_HOST_AFFINITY=0 leaves
+//   the threads where the scheduler puts them.
 static bool parse_cpulist(const char* path, cpu_set_t* out) {
     FILE* f = std::fopen(path, "r");
     if (!f) return false;
@@ -116,8 +130,20 @@ static bool parse_cpulist(const char* path, cpu_set_t* out) {
     return true;
 }
 
-// the L3 domains of the caller's NUMA node, each intersected with the process's affinity mask
-static std::vector<cpu_set_t> callers_l3_domains() {
+// NUMA node that holds the page of `addr` (move_pages(2) in query mode), -1 if the kernel will not say
+int numa_node_of(const void* addr) {
+#if defined(SYS_move_pages)
+    if (!addr) return -1;
+    void* page = reinterpret_cast<void*>(reinterpret_cast<uintptr_t>(addr) & ~(uintptr_t)4095);
+    int status = -1;
+    if (syscall(SYS_move_pages, 0, 1ul, &page, nullptr, &status, 0) == 0 && status >= 0) return status;
+#endif
+    return -1;
+}
+
+// the L3 domains of one NUMA node (`want_node`; < 0: the node of the calling thread), each intersected with the
+// process's affinity mask
+static std::vector<cpu_set_t> l3_domains(int want_node) {
     std::vector<cpu_set_t> out;
     const char* e = std::getenv("GSX_HOST_AFFINITY");
     if (e && e[0] == '0') return out;
@@ -125,6 +151,16 @@ static std::vector<cpu_set_t> callers_l3_domains() {
     cpu_set_t allowed, node;
     if (cpu < 0 || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return out;
     bool found = false;
+    if (want_node >= 0) {
+        char path[96];
+        std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", want_node);
+        cpu_set_t both;
+        found = parse_cpulist(path, &node);
+        if (found) {
+            CPU_AND(&both, &node, &allowed);
+            found = CPU_COUNT(&both) > 0;  // the process may not run there at all: fall back to the caller's node
+        }
+    }
     for (int n = 0; n < 256 && !found; ++n) {
         char path[96];
         std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", n);
@@ -149,10 +185,10 @@ static std::vector<cpu_set_t> callers_l3_domains() {
     return out;
 }
 
-Workers::Workers(int threads) : impl_(new Impl), nthreads_(threads < 1 ? 1 : threads) {
+Workers::Workers(int threads, int numa_node) : impl_(new Impl), nthreads_(threads < 1 ? 1 : threads) {
     impl_->nthreads = nthreads_;
     impl_->slots = new Slot[(size_t)nthreads_];
-    const std::vector<cpu_set_t> doms = nthreads_ > 1 ? callers_l3_domains() : std::vector<cpu_set_t>();
+    const std::vector<cpu_set_t> doms = nthreads_ > 1 ? l3_domains(numa_node) : std::vector<cpu_set_t>();
     // the caller itself sits in one of the domains (it is not moved); start dealing after it
     size_t first = 0;
     const int cpu = sched_getcpu();
@@ -189,6 +225,10 @@ void Workers::run(int parts, void (*fn)(void*, int), void* arg) {
     s.parts = parts;
     s.fn = fn;
     s.arg = arg;
+    for (int t = 0; t < nthreads_; ++t) {
+        s.slots[t].end = (int)((long long)parts * (t + 1) / nthreads_);
+        s.slots[t].next.store((int)((long long)parts * t / nthreads_), std::memory_order_relaxed);
+    }
     uint64_t g;
     {
         std::lock_guard<std::mutex> lk(s.m);  // pairs with the sleepers' predicate check

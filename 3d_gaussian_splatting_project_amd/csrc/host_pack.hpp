@@ -27,7 +27,9 @@ MapLayout map_layout(int w, int h, bool tiled, bool coarse);
 // Fork-join pool: run(n, fn, arg) calls fn(arg, part) for part in [0, n) on the pool's threads and the caller.
 class Workers {
 public:
-    explicit Workers(int threads);  // total parallelism including the calling thread; >= 1
+    // threads: total parallelism including the calling thread (>= 1); numa_node: where the data to work on lives
+    // (< 0: wherever the creating thread runs)
+    explicit Workers(int threads, int numa_node = -1);
     ~Workers();
     Workers(const Workers&) = delete;
     Workers& operator=(const Workers&) = delete;
@@ -39,6 +41,7 @@ private:
     Impl* impl_;
     int nthreads_;
 };
+int numa_node_of(const void* addr);  // NUMA node holding that page, -1 if unknown
 int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HOST_THREADS
 
 // seg dtype codes as in gsx.h: 0 = int32, 1 = int64, 2 = u8 holding label+1, 3 = u8 holding the label.

@@ -1115,8 +1115,10 @@ static void push_view(Ctx* c, const gsx_camera* cam, const MapLayout& L, size_t 
     c->labels_valid = false;
 }
 
-static Workers* host_workers(Ctx* c) {
-    if (!c->workers) c->workers = new (std::nothrow) Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads());
+// near: a buffer the pool is about to read (the first map of a run): the workers are placed on its NUMA node
+static Workers* host_workers(Ctx* c, const void* near = nullptr) {
+    if (!c->workers)
+        c->workers = new (std::nothrow) Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads(), numa_node_of(near));
     return c->workers;  // nullptr (out of memory): single-threaded packing
 }
 
@@ -1141,7 +1143,7 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
         slot.cap = cap;
     }
     if (!slot.ev) GSX_HIP(c, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
-    if (host_pack_map(host_workers(c), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(slot.p)))
+    if (host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(slot.p)))
         return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
     const size_t off = (c->seg_used + 255) / 256 * 256;
     GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + off, slot.p, L.map_bytes, hipMemcpyHostToDevice, c->stream));

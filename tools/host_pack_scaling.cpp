@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <sched.h>
 using namespace gsx;
 int main(int argc,char**argv){
   int T = argc>1?atoi(argv[1]):8; int w=argc>2?atoi(argv[2]):1920,h=argc>3?atoi(argv[3]):1080; int M=argc>4?atoi(argv[4]):24;
@@ -12,7 +13,16 @@ int main(int argc,char**argv){
   for(int m=0;m<M;++m){ maps[m].resize((size_t)w*h); for(size_t i=0;i<maps[m].size();++i) maps[m][i]=(int)((i/ (97+m)) %151)-1; }
   MapLayout L = map_layout(w,h,true,true);
   std::vector<uint8_t> dst(L.map_bytes*4);
-  Workers pool(T);
+  if (getenv("HPS_REMOTE")) {  // run with `taskset -c 0`: the maps were first-touched on node 0.  Now allow every CPU again but
+                               // make this thread run on the other socket, as a migrated main thread would
+    cpu_set_t one, all; CPU_ZERO(&one); CPU_SET(64, &one); sched_setaffinity(0, sizeof one, &one);
+    CPU_ZERO(&all); for (int c = 0; c < 256; ++c) CPU_SET(c, &all);
+    cpu_set_t s1; CPU_ZERO(&s1); for (int c = 64; c < 128; ++c) CPU_SET(c, &s1); for (int c = 192; c < 256; ++c) CPU_SET(c, &s1);
+    sched_setaffinity(0, sizeof all, &all);   // workers inherit "all"
+    (void)s1;
+  }
+  Workers pool(T, getenv("HPS_FOLLOW") ? numa_node_of(maps[0].data()) : -1);
+  printf("node of maps: %d\n", numa_node_of(maps[0].data()));
   for(int rep=0;rep<3;++rep){
     auto t0=std::chrono::steady_clock::now();
     int bad=0;
