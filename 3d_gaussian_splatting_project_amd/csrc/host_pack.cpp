@@ -255,8 +255,8 @@ int default_host_threads() {
 
 // ---- the narrowing copy --------------------------------------------------------------------------------------------
 // bin = label + ADD as an unsigned number: label -1 -> 0, anything below -1 wraps far above `bins`.
-// Rows<T, ADD>::run narrows `rows` rows of 16 pixels (source rows `pitch` elements apart) into rows*16 consecutive
-// bytes and returns non-zero if a bin >= bins was seen.  A scalar form for every dtype, AVX2 forms for the wide ones.
+// rows16<T, ADD> narrows `rows` groups of 16 pixels (source groups `pitch` elements apart) into 16-byte groups `opitch`
+// bytes apart and returns non-zero if a bin >= bins was seen.  A scalar form for every dtype, AVX2 forms for the wide ones.
 template <typename T, unsigned ADD>
 static inline unsigned narrow_n(const T* __restrict__ src, int cnt, unsigned bins, uint8_t* __restrict__ out) {
     unsigned bad = 0;
@@ -269,22 +269,21 @@ static inline unsigned narrow_n(const T* __restrict__ src, int cnt, unsigned bin
 }
 
 template <typename T, unsigned ADD>
-static unsigned rows16_scalar(const T* __restrict__ src, size_t pitch, int rows, unsigned bins, uint8_t* __restrict__ out) {
+static unsigned rows16_scalar(const T* __restrict__ src, size_t pitch, int rows, unsigned bins, uint8_t* __restrict__ out, size_t opitch) {
     unsigned bad = 0;
-    for (int r = 0; r < rows; ++r) bad |= narrow_n<T, ADD>(src + (size_t)r * pitch, 16, bins, out + r * 16);
+    for (int r = 0; r < rows; ++r) bad |= narrow_n<T, ADD>(src + (size_t)r * pitch, 16, bins, out + (size_t)r * opitch);
     return bad;
 }
 
 #if defined(__x86_64__)
 static constexpr int kPrefetchAhead = 8 * 16;  // elements: 8 strips of 16 pixels further along each row
 __attribute__((target("avx2"))) static unsigned rows16_i32_avx2(const int32_t* __restrict__ src, size_t pitch, int rows,
-                                                                 unsigned bins, uint8_t* __restrict__ out) {
+                                                                 unsigned bins, uint8_t* __restrict__ out, size_t opitch) {
     const __m256i one = _mm256_set1_epi32(1);
     __m256i mx = _mm256_setzero_si256();
     for (int r = 0; r < rows; ++r) {
         const int32_t* p = src + (size_t)r * pitch;
-        // a band walks 8 row streams in lock step, one line each per strip: too irregular for the stride prefetcher, and
-        // without help a core stalls on its ~24 outstanding misses (measured 11-18 GB/s per thread); ask 8 strips ahead
+        // ask a little ahead of the hardware prefetcher (the groups of one call are consecutive along a pixel row)
         _mm_prefetch(reinterpret_cast<const char*>(p + kPrefetchAhead), _MM_HINT_T0);
         __m256i a = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p)), one);
         __m256i b = _mm256_add_epi32(_mm256_loadu_si256(reinterpret_cast<const __m256i*>(p + 8)), one);
@@ -292,7 +291,7 @@ __attribute__((target("avx2"))) static unsigned rows16_i32_avx2(const int32_t* _
         // packus saturates, but a value it would change (> 255, or "negative" = below label -1) is flagged bad anyway
         __m256i w = _mm256_permute4x64_epi64(_mm256_packus_epi32(a, b), 0xD8);  // u16: a0..7 | b0..7
         __m128i q = _mm_packus_epi16(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1));
-        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + r * 16), q);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + (size_t)r * opitch), q);
     }
     __m128i m = _mm_max_epu32(_mm256_castsi256_si128(mx), _mm256_extracti128_si256(mx, 1));
     m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0x4E));
@@ -300,8 +299,24 @@ __attribute__((target("avx2"))) static unsigned rows16_i32_avx2(const int32_t* _
     return (unsigned)_mm_cvtsi128_si32(m) >= bins ? 1u : 0u;
 }
 
+// AVX-512 form (Zen 4/5, Skylake-X and later): one 64-byte load, one saturating down-convert per 16 pixels
+__attribute__((target("avx512f"))) static unsigned rows16_i32_avx512(const int32_t* __restrict__ src, size_t pitch, int rows,
+                                                                     unsigned bins, uint8_t* __restrict__ out, size_t opitch) {
+    const __m512i one = _mm512_set1_epi32(1);
+    __m512i mx = _mm512_setzero_si512();
+    for (int r = 0; r < rows; ++r) {
+        const int32_t* p = src + (size_t)r * pitch;
+        _mm_prefetch(reinterpret_cast<const char*>(p + kPrefetchAhead), _MM_HINT_T0);
+        const __m512i a = _mm512_add_epi32(_mm512_loadu_si512(p), one);
+        mx = _mm512_max_epu32(mx, a);
+        // unsigned saturation: a value it would change (> 255, or "negative" = below label -1) is flagged bad anyway
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + (size_t)r * opitch), _mm512_cvtusepi32_epi8(a));
+    }
+    return _mm512_reduce_max_epu32(mx) >= bins ? 1u : 0u;
+}
+
 __attribute__((target("avx2"))) static unsigned rows16_i64_avx2(const int64_t* __restrict__ src, size_t pitch, int rows,
-                                                                 unsigned bins, uint8_t* __restrict__ out) {
+                                                                 unsigned bins, uint8_t* __restrict__ out, size_t opitch) {
     const __m256i one = _mm256_set1_epi64x(1);
     const __m256i idx = _mm256_setr_epi32(0, 2, 4, 6, 1, 3, 5, 7);  // low dwords first, high dwords second
     __m256i mx = _mm256_setzero_si256(), hi_or = _mm256_setzero_si256();
@@ -321,7 +336,7 @@ __attribute__((target("avx2"))) static unsigned rows16_i64_avx2(const int64_t* _
         }
         __m256i w = _mm256_permute4x64_epi64(_mm256_packus_epi32(lo[0], lo[1]), 0xD8);
         __m128i q = _mm_packus_epi16(_mm256_castsi256_si128(w), _mm256_extracti128_si256(w, 1));
-        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + r * 16), q);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + (size_t)r * opitch), q);
     }
     __m128i m = _mm_max_epu32(_mm256_castsi256_si128(mx), _mm256_extracti128_si256(mx, 1));
     m = _mm_max_epu32(m, _mm_shuffle_epi32(m, 0x4E));
@@ -342,23 +357,25 @@ __attribute__((target("avx2"))) static uint32_t coarse_word_avx2(const uint8_t* 
     return (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(val, _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1)));
 }
 static const bool g_avx2 = __builtin_cpu_supports("avx2");
+static const bool g_avx512 = __builtin_cpu_supports("avx512f") && !std::getenv("GSX_HOST_NO_AVX512");
 #else
 static const bool g_avx2 = false;
 static uint32_t coarse_word_avx2(const uint8_t*) { return 0; }
 #endif
 
 template <typename T, unsigned ADD>
-static inline unsigned rows16(const T* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
-    return rows16_scalar<T, ADD>(src, pitch, rows, bins, out);
+static inline unsigned rows16(const T* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    return rows16_scalar<T, ADD>(src, pitch, rows, bins, out, opitch);
 }
 #if defined(__x86_64__)
 template <>
-inline unsigned rows16<int32_t, 1u>(const int32_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
-    return g_avx2 ? rows16_i32_avx2(src, pitch, rows, bins, out) : rows16_scalar<int32_t, 1u>(src, pitch, rows, bins, out);
+inline unsigned rows16<int32_t, 1u>(const int32_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    if (g_avx512) return rows16_i32_avx512(src, pitch, rows, bins, out, opitch);
+    return g_avx2 ? rows16_i32_avx2(src, pitch, rows, bins, out, opitch) : rows16_scalar<int32_t, 1u>(src, pitch, rows, bins, out, opitch);
 }
 template <>
-inline unsigned rows16<int64_t, 1u>(const int64_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out) {
-    return g_avx2 ? rows16_i64_avx2(src, pitch, rows, bins, out) : rows16_scalar<int64_t, 1u>(src, pitch, rows, bins, out);
+inline unsigned rows16<int64_t, 1u>(const int64_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    return g_avx2 ? rows16_i64_avx2(src, pitch, rows, bins, out, opitch) : rows16_scalar<int64_t, 1u>(src, pitch, rows, bins, out, opitch);
 }
 #endif
 
@@ -370,7 +387,10 @@ struct PackJob {
     std::atomic<unsigned> bad{0};
 };
 
-// one band of 8 pixel rows = one 128-B line of every strip (and two rows of coarse cells)
+// one band of 8 pixel rows = one 128-B line of every strip (and two rows of coarse cells).  The source is read ROW BY
+// ROW, start to end (a band is 8 consecutive rows = one contiguous piece of the map): plain streaming, which a core
+// reads at twice the rate of eight row streams walked strip by strip in lock step.  The 16-byte pieces go to the strips'
+// lines (strip_bytes apart), which stay in L1/L2 for the 8 rows of the band; the coarse bytes are made from them at the end.
 template <typename T, unsigned ADD>
 static void pack_band_tiled(PackJob* j, int band) {
     const MapLayout L = j->L;  // by value: the u8 stores below may alias anything reached through a pointer
@@ -378,21 +398,22 @@ static void pack_band_tiled(PackJob* j, int band) {
     uint8_t* const dst = j->dst;
     const T* seg = static_cast<const T*>(j->seg);
     const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
-    const int strips = (L.w + 15) / 16;
+    const int strips = (L.w + 15) / 16, full = L.w / 16;
     unsigned bad = 0;
+    for (int y = y0; y < y1; ++y) {
+        const T* row = seg + (size_t)y * L.w;
+        uint8_t* o = dst + (size_t)y * 16;  // row y of strip 0
+        if (full) bad |= rows16<T, ADD>(row, 16, full, bins, o, (size_t)L.strip_bytes);
+        if (full < strips) {  // ragged last strip: columns past the map hold bin 0
+            uint8_t* e = o + (size_t)full * L.strip_bytes;
+            std::memset(e, 0, 16);
+            bad |= narrow_n<T, ADD>(row + (size_t)full * 16, L.w - full * 16, bins, e);
+        }
+    }
     for (int s = 0; s < strips; ++s) {
         const int x0 = s * 16;
         const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
         uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)y0 * 16;
-        if (cnt == 16) {
-            bad |= rows16<T, ADD>(seg + (size_t)y0 * L.w + x0, (size_t)L.w, y1 - y0, bins, line);
-        } else {
-            for (int y = y0; y < y1; ++y) {
-                uint8_t* o = line + (y - y0) * 16;
-                std::memset(o, 0, 16);
-                bad |= narrow_n<T, ADD>(seg + (size_t)y * L.w + x0, cnt, bins, o);
-            }
-        }
         if (y1 - y0 < 8) std::memset(line + (y1 - y0) * 16, 0, (size_t)(8 - (y1 - y0)) * 16);  // rows past the map: defined bytes
         if (L.cstrip_bytes) {
             // coarse cells of this strip: 4 per cell row; a cell holds the bin its 16 pixels share, else 255
@@ -433,7 +454,7 @@ static void pack_band_rows(PackJob* j, int band) {  // row-major u8 map ("seg_ti
     const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
     const size_t i0 = (size_t)y0 * L.w, i1 = (size_t)y1 * L.w;
     const size_t full = (i1 - i0) / 16;
-    unsigned bad = full ? rows16<T, ADD>(seg + i0, 16, (int)full, j->bins, j->dst + i0) : 0u;
+    unsigned bad = full ? rows16<T, ADD>(seg + i0, 16, (int)full, j->bins, j->dst + i0, 16) : 0u;
     const size_t i = i0 + full * 16;
     if (i < i1) bad |= narrow_n<T, ADD>(seg + i, (int)(i1 - i), j->bins, j->dst + i);
     if (bad) j->bad.fetch_or(1u, std::memory_order_relaxed);
