@@ -105,10 +105,10 @@ def exchange_labels(shard, group=None, to_host=True, out=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     with _stream_of(shard):
         counts = shard.counts_tensor()
-        if world > 1:
+        if _collectives_needed(world):
             dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
         keys = shard.compute_keys()
-        if world > 1:
+        if _collectives_needed(world):
             dist.all_reduce(keys, op=dist.ReduceOp.MAX, group=group)
         return shard.labels(to_host, out=out)
 
@@ -163,6 +163,13 @@ def configure_a2a(ctx, world):
     ctx.set_option("exchange_local", 1)
 
 
+def _collectives_needed(world):
+    """world > 1; or, for rehearsing the real RCCL calls on a one-GPU box, a 1-rank group with GSX_DIST_FORCE_COLLECTIVES=1
+    (every collective then runs for real through RCCL, on this rank alone)."""
+    import os
+    return world > 1 or (dist.is_initialized() and os.environ.get("GSX_DIST_FORCE_COLLECTIVES") == "1")
+
+
 def _all_to_all(out, inp, group):
     if dist.get_backend(group) == "gloo":
         # rehearsal / CPU tests only: gloo has no all_to_all (and no GPU all_gather): stage through the
@@ -194,14 +201,14 @@ def exchange_labels_a2a(shard, group=None, to_host=True, out=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     with _stream_of(shard):
         cnt, fv = shard.planes()
-        if world > 1:
+        if _collectives_needed(world):
             rc, rf = torch.empty_like(cnt), torch.empty_like(fv)
             _all_to_all(rc, cnt, group)
             _all_to_all(rf, fv, group)
         else:
             rc, rf = cnt, fv
         slab = shard.reduce(rc, rf)
-        if world > 1:
+        if _collectives_needed(world):
             full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
             _all_gather_into(full, slab, group)
         else:
@@ -274,25 +281,25 @@ def exchange_labels_sparse(shard, group=None, to_host=True, out=None):
 def _exchange_labels_sparse(shard, group, to_host, out):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     cnt = shard.counts()
-    if world > 1:
+    if _collectives_needed(world):
         rc = torch.empty_like(cnt)
         _all_to_all(rc, cnt, group)
     else:
         rc = cnt
     cand = shard.totals(rc)
-    if world > 1:
+    if _collectives_needed(world):
         cand_all = torch.empty(cand.numel() * world, dtype=cand.dtype, device=cand.device)
         _all_gather_into(cand_all, cand, group)
     else:
         cand_all = cand
     codes = shard.tie_codes(cand_all)
-    if world > 1:
+    if _collectives_needed(world):
         rcodes = torch.empty_like(codes)
         _all_to_all(rcodes, codes, group)
     else:
         rcodes = codes
     slab = shard.resolve(rcodes)
-    if world > 1:
+    if _collectives_needed(world):
         full = torch.empty(slab.numel() * world, dtype=slab.dtype, device=slab.device)
         _all_gather_into(full, slab, group)
     else:
@@ -392,7 +399,7 @@ def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=
     cap = int(cap_views) if cap_views else 1024
     # 1. headers.  Issued on torch's own stream, NOT the ctx stream: it does not have to wait for the maps' DMA.
     mine = shard.header(cap)
-    if world > 1:
+    if _collectives_needed(world):
         heads = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
         _all_gather_into(heads, mine, group)
     else:
@@ -407,7 +414,7 @@ def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=
     with _stream_of(shard):
         # 2. the maps
         pool = shard.pool(chunk)
-        if world > 1:
+        if _collectives_needed(world):
             pool_all = shard.pool_all(world * chunk)
             _all_gather_into(pool_all, pool, group)
         else:
@@ -416,7 +423,7 @@ def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=
         shard.import_all(part_views, np.arange(world, dtype=np.int64) * chunk, blobs, pool_all)
         slab = shard.slab_labels(rank, world)
         # 4. the labels
-        if world > 1:
+        if _collectives_needed(world):
             full = shard.labels_all(slab.numel() * world)
             _all_gather_into(full, slab, group)
         else:
