@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised soak of the labeler against the oracle (GPU box): scenes large enough for whole waves to be culled,
 cameras inside and outside the scene, class maps with every mix of uniform and boundary cells, sizes that are not
-multiples of 4 / 16, random tuning options, single launch and planes path.  Usage: tests/soak.py SEED TRIALS"""
+multiples of 4 / 16, random tuning options, single launch and planes path; maps handed over from the host (int32 / int64 /
+uint8 labels / packed u8, 1-16 packer threads), from the device, one by one or batched; protocol v4's export -> import
+-> slab votes assembled for a random number of slabs.  Usage: tests/soak.py SEED TRIALS"""
 import importlib
 import os
 import sys
@@ -14,6 +16,8 @@ sys.path.insert(0, ROOT)
 gsx = importlib.import_module("3d_gaussian_splatting_project_amd.labeler")
 scene = importlib.import_module("3d_gaussian_splatting_project_amd.scene")
 import oracle  # noqa: E402  (the checker)
+import torch  # noqa: E402
+dist = importlib.import_module("3d_gaussian_splatting_project_amd.dist")
 
 seed, trials = int(sys.argv[1]), int(sys.argv[2])
 rng = np.random.default_rng(seed)
@@ -27,6 +31,7 @@ with gsx.Context(0) as c:
         opts = {"spatial_sort": int(rng.random() < 0.8), "seg_tiled": int(rng.random() < 0.9), "vote_unroll": int(rng.choice([2, 4, 8])),
                 "flat_project": int(rng.random() < 0.85), "wave_cull": int(rng.random() < 0.8), "seg_coarse": int(rng.random() < 0.8),
                 "xcd_swizzle": int(rng.choice([0, 1, 4, 32])), "fast_div": int(rng.random() < 0.3), "lds_batch": int(rng.random() < 0.2)}
+        opts["host_threads"] = int(rng.choice([1, 3, 16]))
         for k, v in opts.items():
             c.set_option(k, v)
         spread = float(rng.choice([0.3, 2.0, 8.0, 40.0]))
@@ -61,8 +66,22 @@ with gsx.Context(0) as c:
         want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
         c.upload_positions(pos)
         c.vote_begin(C, 0, V)
-        for cam, seg, sz in zip(cams, segs, sizes):
-            c.vote_view(cam, seg, sz)
+        how = rng.random()
+        if how < 0.15 and same and all(sz == sizes[0] for sz in sizes) and all(s_.shape == segs[0].shape and s_.dtype == segs[0].dtype for s_ in segs):
+            c.vote_views_device(cams, torch.from_numpy(np.stack(segs)).cuda(), sizes[0])       # batched device hand-over
+        else:
+            for cam, seg, sz in zip(cams, segs, sizes):
+                r = rng.random()
+                if r < 0.25:
+                    c.vote_view(cam, torch.from_numpy(np.ascontiguousarray(seg)).cuda(), sz)   # device map
+                elif r < 0.4:
+                    c.vote_view(cam, seg.astype(np.int64), sz)
+                elif r < 0.5 and seg.min() >= 0 and C <= 255:
+                    c.vote_view(cam, seg.astype(np.uint8), sz)                                 # uint8 = labels
+                elif r < 0.6:
+                    c.vote_view(cam, (seg + 1).astype(np.uint8), sz, packed_u8=True)           # the packed form
+                else:
+                    c.vote_view(cam, seg, sz)
         got = c.vote_finalize()
         culled_total += c.vote_culled(reset=True)
         assert np.array_equal(got, want), ("labels kernel", seed, trial, n, V, C, opts)
@@ -70,6 +89,22 @@ with gsx.Context(0) as c:
         c.vote_flush()
         c.vote_tiebreak_keys()
         assert np.array_equal(c.vote_labels_from_keys(), want), ("planes path", seed, trial, n, V, C, opts)
+        if rng.random() < 0.5:      # protocol v4 on one context: its own pool re-imported in 1-3 parts, slabs assembled by hand
+            world = int(rng.integers(1, 6))
+            ptr, used, blobs = c.vote_export(0)
+            pool = dist.device_bytes_tensor(ptr, max(used, 256), 0).clone()
+            cuts = sorted(set([0, V] + [int(x) for x in rng.integers(0, V + 1, size=2)]))
+            parts = [b - a for a, b in zip(cuts, cuts[1:])]
+            c.vote_import(parts, [0] * len(parts), blobs, pool.data_ptr(), pool.numel())
+            slabs = []
+            for r_ in range(world):
+                sn = c.vote_slab_labels(r_, world)
+                kp, _ = c.keys_device()
+                c.synchronize()
+                slabs.append(dist.device_words_tensor(kp, sn, 0).clone())
+            full = torch.cat(slabs)
+            torch.cuda.synchronize()
+            assert np.array_equal(c.vote_labels_from_sorted(full.data_ptr()), want), ("slab votes", seed, trial, n, V, C, world, opts)
         if trial % 20 == 0:
             print(f"trial {trial}/{trials} ok  ({time.time() - t0:.0f} s, {culled_total} wave-views culled so far)", flush=True)
 print(f"SOAK OK: seed {seed}, {trials} trials, {culled_total} wave-views culled, {time.time() - t0:.0f} s")
