@@ -94,6 +94,7 @@ _SIGS = {
     "gsx_upload_sh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "gsx_num_splats": (C.c_int64, [C.c_void_p]),
     "gsx_render_view": (C.c_int, [C.c_void_p, C.POINTER(Camera), C.c_int32, C.c_int32, C.c_void_p]),
+    "gsx_render_views": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "gsx_render_image_device": (C.c_void_p, [C.c_void_p]),
     "gsx_render_num_pairs": (C.c_int64, [C.c_void_p]),
     "gsx_render_num_pairs_consumed": (C.c_int64, [C.c_void_p]),

@@ -144,6 +144,7 @@ void gsx_destroy(gsx_ctx* ctx) {
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
                            &c->r_offset, &c->r_rec0, &c->r_rec1, &c->r_rec2, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_sat, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
         b->release();
+    gsx::render_release_twin(c);
     gsx::vote_release_host(c);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -441,6 +442,10 @@ int64_t gsx_num_splats(const gsx_ctx* ctx) {
 int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out) {
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::render_view(c, cam, width, height, rgba_out); });
+}
+int gsx_render_views(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, int32_t width, int32_t height, float* const* rgba_out) {
+    CTX_OR_FAIL(ctx);
+    return gsx::guard(c, __func__, [&] { return gsx::render_views(c, n, cams, width, height, rgba_out); });
 }
 void* gsx_render_image_device(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);

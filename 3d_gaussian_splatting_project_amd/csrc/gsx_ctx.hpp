@@ -32,23 +32,33 @@ int fail(Ctx* c, int code, const char* fmt, ...);
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool owned = true;  // false: an alias of another context's buffer (gsx_render_views' twin): never freed or regrown here
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap), owned(o.owned) { o.p = nullptr; o.cap = 0; o.owned = true; }
     DevBuf& operator=(DevBuf&& o) noexcept {
         if (this != &o) {
             release();
             p = o.p;
             cap = o.cap;
+            owned = o.owned;
             o.p = nullptr;
             o.cap = 0;
+            o.owned = true;
         }
         return *this;
+    }
+    void alias(const DevBuf& o) {  // view of o's memory; o must outlive this
+        release();
+        p = o.p;
+        cap = o.cap;
+        owned = false;
     }
     ~DevBuf() { release(); }
     hipError_t ensure(size_t bytes) {  // contents are NOT preserved on growth
         if (bytes <= cap) return hipSuccess;
+        if (!owned) return hipErrorInvalidValue;  // an alias cannot grow
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -57,9 +67,10 @@ struct DevBuf {
         return e;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p && owned) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        owned = true;
     }
     template <class T>
     T* as() const { return reinterpret_cast<T*>(p); }
@@ -193,6 +204,7 @@ struct Ctx {
     int opt_render_phases = 2;           // depth phases per frame (1 = bin and sort every pair at once)
     int opt_render_phase_ratio = 4;      // phase p ends at n / ratio^(K-1-p) splats (front to back)
     unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
+    Ctx* twin = nullptr;                 // gsx_render_views: a second stream + per-frame buffers, aliasing this context's scene
     size_t r_pair_cap = 0;               // capacity (pairs) of r_keys*/r_vals*: grown when a phase overflows it, the frame is redone
     unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)
     DevBuf r_d0, r_d1, r_d2, r_d3;       // level-1 sort ping-pong (bucket, splat)
@@ -256,6 +268,8 @@ int upload_splats(Ctx* c, int64_t n, const float* xyz, const float* scale, const
                   const float* f_dc, const int32_t* labels);
 int upload_sh(Ctx* c, const float* f_rest, int deg);
 int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out);
+int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* const* rgba_out);
+void render_release_twin(Ctx* c);
 int hit_test(Ctx* c, const gsx_camera* cam, int W, int H, double x, double y, int32_t* label_out, int64_t* index_out);
 int render_debug(Ctx* c, uint8_t* buffer_out, uint32_t* order_out, uint32_t* tex_out, uint32_t* bucket_out);
 void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, int img_w, int img_h);

@@ -153,6 +153,34 @@ def test_depth_phases_do_not_change_the_frame(gsx):
     assert pairs[(2, 0)] < 0.7 * pairs[(1, 0)] and pairs[(4, 0)] < pairs[(2, 0)]
 
 
+def test_render_views_two_frames_in_flight(gsx):
+    """gsx_render_views renders even views on the context's stream and odd views on its twin stream (own per-frame
+    buffers, shared scene) from a second host thread: bit for bit the frames of one-at-a-time gsx_render_view, any number
+    of views, with and without the SH colour path, before and after the scene is replaced."""
+    W, H = 640, 360
+    with gsx.Context(0) as c:
+        for n, deg, seed in ((30_000, 0, 5), (45_000, 2, 6)):
+            xyz = scene.make_positions(n, seed)
+            a = scene.make_splat_attributes(n, seed, sh_degree=max(deg, 1))
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            if deg:
+                c.upload_sh(a["f_rest"][:, :3 * ((deg + 1) ** 2 - 1)], deg)
+            cams = scene.make_cameras(7, W, H, convention="c2w")
+            single = [c.render_view(cam, W, H) for cam in cams]
+            pairs = 0
+            for cam in cams:
+                c.render_view(cam, W, H, to_host=False)
+                pairs += c.render_num_pairs()
+            for count in (7, 2, 1):
+                many = c.render_views(cams[:count], W, H)
+                assert many.shape == (count, H, W, 4)
+                for k in range(count):
+                    assert np.array_equal(many[k], single[k]), (n, deg, count, k)
+            c.render_views(cams, W, H, to_host=False)
+            assert c.render_num_pairs() == pairs
+        assert c.render_views([], W, H, to_host=False) is None
+
+
 def test_export_splat_file(ctx, g, tmp_path):
     ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
     path = str(tmp_path / "scene.splat")
