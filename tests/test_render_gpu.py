@@ -181,6 +181,26 @@ def test_render_views_two_frames_in_flight(gsx):
         assert c.render_views([], W, H, to_host=False) is None
 
 
+def test_pair_count_beyond_31_bits_is_an_error_not_a_wrapped_offset(gsx):
+    """the (tile, splat) pair count of a close-up of a very large scene can pass 2^31 (offsets are 32 bit).
+    300 k splats that each cover the whole 1080p frame = 2.4e9 pairs in a single depth phase: the 64-bit grand total of
+    the scan must turn that into GSX_E_RANGE (ValueError) - never into wrapped offsets and out-of-bounds writes."""
+    n, W, H = 300_000, 1920, 1080
+    rng = np.random.default_rng(3)
+    xyz = (rng.normal(size=(n, 3)) * 0.05).astype(np.float32)
+    scale = np.full((n, 3), np.log(50.0), np.float32)           # far wider than the frame: the axes are capped at 1024 px
+    rot = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))
+    cam = scene.make_cameras(3, W, H, convention="c2w")[0]
+    with gsx.Context(0) as c:
+        c.set_option("render_phases", 1)
+        c.upload_splats(xyz, scale, rot, np.zeros(n, np.float32), np.zeros((n, 3), np.float32))
+        with pytest.raises(ValueError, match="render_phases"):
+            c.render_view(cam, W, H, to_host=False)
+        # the context stays usable
+        c.upload_splats(xyz[:1000], scale[:1000] - np.float32(np.log(500.0)), rot[:1000], np.zeros(1000, np.float32), np.zeros((1000, 3), np.float32))
+        assert np.isfinite(c.render_view(cam, W, H)).all()
+
+
 def test_export_splat_file(ctx, g, tmp_path):
     ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
     path = str(tmp_path / "scene.splat")
