@@ -190,6 +190,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
+    else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
         if ((int)value != c->opt_host_threads) {

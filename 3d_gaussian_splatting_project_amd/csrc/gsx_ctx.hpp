@@ -167,6 +167,8 @@ struct Ctx {
     // host hand-over (vote.hip): worker pool, pinned ring for the maps, pinned landing zone for the labels
     Workers* workers = nullptr;
     int opt_host_threads = 0;  // 0: default_host_threads()
+    int opt_host_pack = 1;     // 1: host maps are narrowed to u8 by the workers (2.2 MB/map over PCIe); 0: raw copy + GPU pack kernel (8.3 MB/map)
+    DevBuf dstage[kPinSlots];  // host_pack = 0: device-side landing zone of the raw map of each ring slot
     PinSlot ring[kPinSlots];
     int ring_next = 0;
     void* h_labels = nullptr;  // pinned: n int32 labels + one int (the error flag) land here before the caller's array

@@ -1116,6 +1116,8 @@ static void push_view(Ctx* c, const gsx_camera* cam, const MapLayout& L, size_t 
 }
 
 // near: a buffer the pool is about to read (the first map of a run): the workers are placed on its NUMA node
+static void launch_pack(Ctx* c, const PackArgs& a, int jobs, int seg_dtype, bool vec, long long cells);
+
 static Workers* host_workers(Ctx* c, const void* near = nullptr) {
     if (!c->workers)
         c->workers = new (std::nothrow) Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads(), numa_node_of(near));
@@ -1143,6 +1145,40 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
         slot.cap = cap;
     }
     if (!slot.ev) GSX_HIP(c, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    if (!c->opt_host_pack) {
+        // The alternative this library does NOT default to (kept for hosts short of cores, and as the A/B of DESIGN.md §3):
+        // the raw map crosses PCIe (8.3 MB instead of 2.2 MB per 1080p int32 map) and the fused kernel packs it on the GPU.
+        // The range check is then the device-side one (reported with the labels).
+        const size_t esz = seg_dtype == GSX_SEG_I32 ? 4 : seg_dtype == GSX_SEG_I64 ? 8 : 1;
+        const size_t raw = esz * (size_t)seg_w * (size_t)seg_h;
+        if (slot.cap < raw) {
+            GSX_HIP(c, hipHostFree(slot.p));
+            slot.p = nullptr;
+            slot.cap = 0;
+            GSX_HIP(c, hipHostMalloc(&slot.p, raw, hipHostMallocDefault));
+            slot.cap = raw;
+        }
+        DevBuf& land = c->dstage[c->ring_next];
+        GSX_HIP(c, land.ensure(raw));
+        host_copy(host_workers(c, seg), slot.p, seg, raw);
+        GSX_HIP(c, hipMemcpyAsync(land.p, slot.p, raw, hipMemcpyHostToDevice, c->stream));
+        const size_t off = (c->seg_used + 255) / 256 * 256;
+        PackArgs a{};
+        a.src[0] = land.p;
+        a.dst[0] = c->segpool.as<uint8_t>() + off;
+        a.view[0] = c->first_view + (int)c->views.size();
+        a.w = L.w, a.h = L.h, a.strip_bytes = L.strip_bytes, a.cstrip_bytes = L.cstrip_bytes, a.cw = L.cw, a.ch = L.ch;
+        a.bins = c->bins;
+        a.coarse_off = (unsigned)L.coarse_off;
+        a.err = c->errflag.as<int>();
+        launch_pack(c, a, 1, seg_dtype, seg_w % 4 == 0, (long long)L.cw * L.ch);
+        GSX_HIP(c, hipGetLastError());
+        GSX_HIP(c, hipEventRecord(slot.ev, c->stream));  // after the kernel: it is the last reader of this slot's landing zone
+        slot.busy = true;
+        c->ring_next = (c->ring_next + 1) % kPinSlots;
+        push_view(c, cam, L, off, img_w, img_h);
+        return GSX_OK;
+    }
     if (host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(slot.p)))
         return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
     const size_t off = (c->seg_used + 255) / 256 * 256;
@@ -1152,6 +1188,16 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
     c->ring_next = (c->ring_next + 1) % kPinSlots;
     push_view(c, cam, L, off, img_w, img_h);
     return GSX_OK;
+}
+
+static void launch_pack(Ctx* c, const PackArgs& a, int jobs, int seg_dtype, bool vec, long long cells) {
+    using K = void (*)(PackArgs);
+    static const K table[4][2] = {{seg_pack_fused_kernel<int32_t, 1, false>, seg_pack_fused_kernel<int32_t, 1, true>},
+                                  {seg_pack_fused_kernel<int64_t, 1, false>, seg_pack_fused_kernel<int64_t, 1, true>},
+                                  {seg_pack_fused_kernel<uint8_t, 0, false>, seg_pack_fused_kernel<uint8_t, 0, true>},
+                                  {seg_pack_fused_kernel<uint8_t, 1, false>, seg_pack_fused_kernel<uint8_t, 1, true>}};
+    ProfScope ps(c, "seg_pack");
+    hipLaunchKernelGGL(table[seg_dtype][vec ? 1 : 0], dim3(grid_for(cells), jobs), dim3(kBlock), 0, c->stream, a);
 }
 
 // Device maps (all of one geometry and dtype): kPackBatch maps per launch of the fused pack kernel.  Nothing is
@@ -1183,13 +1229,7 @@ int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* 
         a.bins = c->bins;
         a.coarse_off = (unsigned)L.coarse_off;
         a.err = c->errflag.as<int>();
-        using K = void (*)(PackArgs);
-        static const K table[4][2] = {{seg_pack_fused_kernel<int32_t, 1, false>, seg_pack_fused_kernel<int32_t, 1, true>},
-                                      {seg_pack_fused_kernel<int64_t, 1, false>, seg_pack_fused_kernel<int64_t, 1, true>},
-                                      {seg_pack_fused_kernel<uint8_t, 0, false>, seg_pack_fused_kernel<uint8_t, 0, true>},
-                                      {seg_pack_fused_kernel<uint8_t, 1, false>, seg_pack_fused_kernel<uint8_t, 1, true>}};
-        ProfScope ps(c, "seg_pack");
-        hipLaunchKernelGGL(table[seg_dtype][vec ? 1 : 0], dim3(grid_for(cells), m), dim3(kBlock), 0, c->stream, a);
+        launch_pack(c, a, m, seg_dtype, vec, cells);
         GSX_HIP(c, hipGetLastError());
     }
     return GSX_OK;
@@ -1206,6 +1246,7 @@ void vote_release_host(Ctx* c) {
         if (s.p) (void)hipHostFree(s.p);
         s = PinSlot{};
     }
+    for (DevBuf& b : c->dstage) b.release();
     for (hipEvent_t& e : c->h_ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;

@@ -159,7 +159,10 @@ int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t 
  * The map is read during the call (worker threads narrow it to the u8 on-device form inside pinned memory and
  * check the label range: GSX_E_RANGE fails THIS call and stages nothing); the DMA into the pool is asynchronous
  * and nothing is synchronised: 200 calls cost the host pass over the maps, ~2.2 MB of PCIe traffic per 1080p map.
- * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool. */
+ * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool.
+ * Option "host_pack" = 0 selects the alternative hand-over: the workers only copy the raw map into pinned memory, the raw
+ * bytes cross PCIe (4x as many for int32) and the fused kernel of gsx_vote_view_device packs them; the range check is
+ * then the deferred device-side one.  Measured slower on the GPU box; for hosts short of cores. */
 int gsx_vote_view(gsx_ctx* ctx, const gsx_camera* cam, const void* seg, int32_t seg_dtype, int32_t seg_w,
                   int32_t seg_h, int32_t img_w, int32_t img_h);
 /* same, seg is a DEVICE pointer (e.g. the segmentation model's output tensor on this GPU): one fused kernel on
