@@ -1002,17 +1002,26 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
     int rc_twin = GSX_OK;
     unsigned long long P[2] = {0, 0}, used[2] = {0, 0};
     std::thread other([&] {
-        (void)hipSetDevice(t->device);
-        for (int k = 1; k < n && rc_twin == GSX_OK; k += 2) {
-            rc_twin = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
-            P[1] += t->r_P;
-            used[1] += t->r_consumed;
+        try {  // nothing may escape a thread's entry function
+            (void)hipSetDevice(t->device);
+            for (int k = 1; k < n && rc_twin == GSX_OK; k += 2) {
+                rc_twin = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
+                P[1] += t->r_P;
+                used[1] += t->r_consumed;
+            }
+        } catch (...) {
+            rc_twin = fail(t, GSX_E_INVALID, "render_views: the second stream's host thread failed (out of host memory?)");
         }
     });
-    for (int k = 0; k < n && rc == GSX_OK; k += 2) {
-        rc = render_view(c, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
-        P[0] += c->r_P;
-        used[0] += c->r_consumed;
+    try {
+        for (int k = 0; k < n && rc == GSX_OK; k += 2) {
+            rc = render_view(c, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
+            P[0] += c->r_P;
+            used[0] += c->r_consumed;
+        }
+    } catch (...) {
+        other.join();  // never leave a joinable thread behind
+        throw;
     }
     other.join();
     if (rc == GSX_OK && rc_twin != GSX_OK) {

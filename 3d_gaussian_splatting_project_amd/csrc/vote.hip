@@ -1074,6 +1074,7 @@ static int pool_reserve(Ctx* c, size_t need) {
 static int view_prologue(Ctx* c, const char* who, const void* cams, const void* seg, int n, int seg_dtype, int seg_w, int seg_h,
                          int img_w, int img_h, MapLayout& L) {
     if (!c->vote_begun) return fail(c, GSX_E_STATE, "%s before vote_begin", who);
+    if (c->pool_base) return fail(c, GSX_E_STATE, "%s after gsx_vote_import: the run's views are final; start the next one with gsx_vote_begin", who);
     if (!cams || !seg) return fail(c, GSX_E_INVALID, "%s: NULL argument", who);
     if (seg_w < 1 || seg_h < 1 || img_w < 1 || img_h < 1)
         return fail(c, GSX_E_INVALID, "%s: sizes must be positive (seg %dx%d, image %dx%d)", who, seg_w, seg_h, img_w, img_h);

@@ -553,6 +553,8 @@ def test_gather_exchange_on_one_gpu(gsx):
                     assert np.array_equal(shards[r].finish(full), want), (n, V, spatial, r)
                 # an imported context holds every view: a plain finalize on it is the single-GPU result
                 assert np.array_equal(ctxs[1].vote_finalize(), want)
+                with pytest.raises(gsx.GsxError):                    # ... and its set of views is final
+                    ctxs[1].vote_view(cams_all[0], segs_all[0], sizes_all[0])
             finally:
                 for c in ctxs:
                     c.close()
