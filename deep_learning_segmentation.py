@@ -11,7 +11,8 @@ itself writes next to every segmented image (reference line 165) instead of runn
 
 Added flags: --segmap_dir DIR, --n_classes C (default: 150 for the ADE20K models, 80 for YOLO), --gpus N
 (informational).  Several GPUs: `python -m torch.distributed.run --nproc-per-node N deep_learning_segmentation.py
-...` — every rank votes its contiguous block of the cameras and the vote histogram is exchanged over RCCL.
+...` — every rank segments and stages its contiguous block of the cameras, the packed class maps are all-gathered over
+RCCL and every rank votes its slab of the Gaussians (3d_gaussian_splatting_project_amd/dist.py, protocol v4).
 """
 import argparse
 import importlib
@@ -69,7 +70,11 @@ def initialize_model(model_type, device):
 
 
 def segment_image(image_path, output_dir, processor, model, device, model_type):
-    """int32 (H, W) class map of one image, -1 = no class; also saved as <image>_segmap.npy."""
+    """int32 (H, W) class map of one image, -1 = no class; also saved as <image>_segmap.npy.
+    OUT OF SCOPE of this build: kept minimal so that the CLI still runs end to end where the
+    networks' weights are available; it cannot be tested here (no weights, no network).  The hot path only depends on its
+    OUTPUT contract (a 2-D integer map), which `--segmap_dir` feeds directly.  Nearest-neighbour resizes use
+    torch's legacy 'nearest' (source index = floor(dst * scale)), the rule of the reference's cv2.INTER_NEAREST."""
     import torch
     from PIL import Image
     os.makedirs(output_dir, exist_ok=True)
