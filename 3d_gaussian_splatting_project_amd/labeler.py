@@ -404,6 +404,29 @@ class Context:
         return n.value, ms.value
 
 
+def bind_to_gpu_numa_node(device=0):
+    """One process per GPU: keep this process (and every thread it starts from now on) on the CPUs of the NUMA node the
+    GPU hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist), so that the segmentation maps it allocates, the pinned
+    staging ring and the packer threads all sit next to the GPU's PCIe root.  Returns the CPU set, or None when the
+    kernel does not expose the topology or the process may not run there (then nothing is changed)."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        txt = open(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus or cpus == os.sched_getaffinity(0):
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpus
+    except Exception:
+        return None
+
+
 def cull_planes(camera):
     """The five world-space culling planes of one view (test hook, host only): array (5, 5) = unit normal A, offset B,
     margin slope M; a sphere (c, r) is skipped when A.c + B > r + M * (|c|_1 + r) for one of them."""

@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
     ap.add_argument("--side-steps", type=int, default=3, help="steps of each side measurement at N=1 (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event kernel timing")
+    ap.add_argument("--no-numa-bind", action="store_true",
+                    help="do not bind this process to the CPUs of its GPU's NUMA node (one process per GPU: maps, pinned staging and "
+                         "packer threads next to the GPU's PCIe root)")
     return ap.parse_args()
 
 
@@ -176,6 +179,7 @@ def main():
 
     device = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
+    bound = None if args.no_numa_bind else pkg.bind_to_gpu_numa_node(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -426,6 +430,7 @@ def main():
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
                        "wave_views_culled_fraction": round(culled_frac, 4),
+                       "bound_to_gpu_numa_node": None if bound is None else f"{len(bound)} CPUs",
                        "setup_seconds": round(setup_s, 1),
                        "exchanged_labels_equal_single_gpu_vote": labels_check},
             "roofline": roofline,

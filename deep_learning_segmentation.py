@@ -134,6 +134,8 @@ def assign_labels(gaussians, cameras, input_dir, output_dir, model_type="mask2fo
     world, rank = _world()
     own = ctx is None
     ctx = ctx or gsx.Context()
+    if own:
+        gsx.bind_to_gpu_numa_node(ctx.device)   # maps, pinned staging and packer threads next to this rank's GPU
     try:
         # one process per GPU: this rank segments and stages its contiguous block of the processed cameras; the packed
         # maps are then all-gathered and every rank votes its slab of the Gaussians (dist.py, protocol v4).  A rank
