@@ -185,14 +185,16 @@ def _all_to_all(out, inp, group):
         dist.all_to_all_single(out, inp, group=group)
 
 
-def _all_gather_into(full, part, group):
+def _all_gather_into(full, part, group, async_op=False):
+    """-> a Work to wait() on when async_op and the backend can do it, else None (the gather has been completed)."""
     if dist.get_backend(group) == "gloo":
         world = dist.get_world_size(group)
         host = part.cpu().contiguous()
         parts = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(parts, host, group=group)
         full.copy_(torch.cat(parts).to(full.device))
-    else:
+        return None
+    return dist.all_gather_into_tensor(full, part.contiguous(), group=group, async_op=async_op) if async_op else \
         dist.all_gather_into_tensor(full, part.contiguous(), group=group)
 
 
@@ -341,6 +343,14 @@ class GpuGatherShard(_GpuShard):
             self._pool_all = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", self.ctx.device))
         return self._pool_all[:nbytes]
 
+    def staged(self):
+        """(views staged so far, pool bytes in use)"""
+        _, used, _ = self.ctx.vote_export(0, blobs=False)
+        return self.ctx.vote_num_views(), used
+
+    def device(self):
+        return torch.device("cuda", self.ctx.device)
+
     def import_all(self, part_views, part_offsets, blobs, pool_all):
         self.ctx.vote_import(part_views, part_offsets, blobs, pool_all.data_ptr(), pool_all.numel())
 
@@ -376,6 +386,12 @@ class HostGatherShard:
 
     def pool_all(self, nbytes):
         return torch.empty(nbytes, dtype=torch.uint8)
+
+    def staged(self):
+        return self.shard.staged()
+
+    def device(self):
+        return torch.device("cpu")
 
     def import_all(self, part_views, part_offsets, blobs, pool_all):
         self.shard.import_all(part_views, part_offsets, blobs, pool_all.numpy())
@@ -429,6 +445,118 @@ def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=
         else:
             full = slab
         return shard.finish(full, to_host, out=out)
+
+
+class GatherPipeline:
+    """Protocol v4 with the all-gather of the packed maps OVERLAPPED with the hand-over of the later views.
+
+        pipe = GatherPipeline(shard, total_views)          # after gsx_vote_begin
+        for view in my block:  ctx.vote_view(...);  pipe.after_view()
+        labels = pipe.finish(out=...)
+
+    Every rank must own the block view_range(total_views, rank, world) of views.  The ranks' blocks are cut into C chunks
+    of m views; as soon as a rank has staged the views of chunk j it joins all_gather number j (async, on the ctx stream:
+    the DMAs of the later views keep flowing, RCCL's stream picks the chunk up behind the copies that fill it).  The
+    sequence of collectives is a function of (total_views, world) alone: one agreement all_gather (the ranks' map strides),
+    C chunk all_gathers, the header all_gather, the labels all_gather - identical on every rank whatever happens locally.
+    If the maps are not of ONE geometry (strides differ between ranks, or a rank finds its own pool irregular at the end),
+    every rank learns it from gathered data and all fall back to the plain gather of exchange_labels_gather."""
+
+    def __init__(self, shard, total_views, group=None, chunks=4):
+        self.shard, self.group, self.total = shard, group, int(total_views)
+        on = dist.is_initialized()
+        self.world = dist.get_world_size(group) if on else 1
+        self.rank = dist.get_rank(group) if on else 0
+        self.active = _collectives_needed(self.world)
+        self.n = [hi - lo for lo, hi in (view_range(self.total, r, self.world) for r in range(self.world))]
+        n_max = max(self.n) if self.n else 0
+        self.m = max(1, -(-n_max // max(1, int(chunks))))       # views per chunk
+        self.C = -(-n_max // self.m) if n_max else 0            # chunk all_gathers every rank will issue
+        self.stride = None       # bytes per staged map, agreed by all ranks; 0: no pipelining (fallback)
+        self.next_chunk = 0
+        self.works = []
+        self.pool_all = None
+        self.pool_src = None
+
+    # -- agreement on the map stride: the first collective of every rank -------------------------------------------------
+    def _agree(self):
+        nv, used = self.shard.staged()
+        mine = used // nv if nv and used % nv == 0 else (-1 if nv == 0 else 0)   # -1: no view yet (no opinion); 0: irregular
+        dev = self.shard.device()
+        t = torch.tensor([mine], dtype=torch.int64, device=dev)
+        alls = torch.empty(self.world, dtype=torch.int64, device=dev)
+        _all_gather_into(alls, t, self.group)
+        vals = [int(v) for v in alls.cpu().tolist()]
+        have = [v for v in vals if v >= 0]
+        self.stride = have[0] if have and all(v == have[0] and v > 0 and v % 256 == 0 for v in have) else 0
+        if self.stride:
+            with _stream_of(self.shard):
+                need = self.C * self.m * self.stride
+                self.pool_src = self.shard.pool(need)                     # reserves: every chunk reads m * stride bytes
+                self.pool_all = self.shard.pool_all(self.world * need)
+
+    def _issue(self, j):
+        if self.stride:
+            cb = self.m * self.stride
+            with _stream_of(self.shard):
+                w = _all_gather_into(self.pool_all[j * self.world * cb:(j + 1) * self.world * cb], self.pool_src[j * cb:(j + 1) * cb],
+                                     self.group, async_op=True)
+            if w is not None:
+                self.works.append(w)
+        self.next_chunk = j + 1
+
+    def after_view(self):
+        if not self.active:
+            return
+        nv, _ = self.shard.staged()
+        if self.stride is None:
+            self._agree()
+        me = self.n[self.rank]
+        while self.next_chunk < self.C and nv >= min((self.next_chunk + 1) * self.m, me):
+            self._issue(self.next_chunk)
+
+    def finish(self, to_host=True, out=None):
+        shard, world, rank = self.shard, self.world, self.rank
+        if not self.active:
+            return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
+        if self.stride is None:
+            self._agree()                                   # a rank without views gets here first
+        while self.next_chunk < self.C:
+            self._issue(self.next_chunk)
+        # header: counts, bytes, blobs - and whether my pool is what the chunk schedule assumed
+        nv, used = shard.staged()
+        regular = bool(self.stride) and nv == self.n[rank] and used == nv * self.stride
+        cap = max(1, max(self.n))
+        mine = shard.header(cap)
+        flag = torch.tensor([1 if regular else 0], dtype=torch.uint8, device=mine.device)
+        mine = torch.cat([mine, flag])
+        heads = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+        _all_gather_into(heads, mine, self.group)
+        heads = heads.cpu().numpy().reshape(world, -1)
+        counts = heads[:, :_HDR].copy().view(np.int64).reshape(world, 2)
+        part_views = counts[:, 0].astype(np.int64)
+        ok = bool(heads[:, -1].all()) and [int(v) for v in part_views] == self.n
+        with _stream_of(shard):                             # Work.wait() makes the CURRENT stream wait: it must be the ctx stream,
+            for w in self.works:                            # on which the import's uploads and the slab vote are queued
+                w.wait()
+        self.works = []
+        if not ok:                                          # every rank sees the same flags: all take the plain path together
+            return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
+        blobs = np.concatenate([heads[r, _HDR:_HDR + 256 * int(part_views[r])] for r in range(world)])
+        cb = self.m * self.stride
+        pv, po = [], []
+        for r in range(world):                              # global view order = rank-major, chunk-minor
+            for j in range(self.C):
+                k = min(max(self.n[r] - j * self.m, 0), self.m)
+                if k:
+                    pv.append(k)
+                    po.append((j * (world - 1) + r) * cb)   # chunk j of rank r sits at (j*world + r)*cb; its blobs say j*cb + ..
+        with _stream_of(shard):
+            shard.import_all(np.asarray(pv, np.int32), np.asarray(po, np.int64), blobs, self.pool_all[:self.C * world * cb])
+            slab = shard.slab_labels(rank, world)
+            full = shard.labels_all(slab.numel() * world)
+            _all_gather_into(full, slab, self.group)
+            return shard.finish(full, to_host, out=out)
 
 
 def view_range(n_views_total, rank, world):

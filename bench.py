@@ -56,9 +56,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="Gaussians in the all-core CPU-baseline sample (0 = skip)")
     ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
     ap.add_argument("--render-splats", type=int, default=3_000_000)
-    ap.add_argument("--exchange", default="gather", choices=["gather", "sparse", "a2a", "allreduce"],
-                    help="multi-GPU protocol: all-gather of the packed maps + Gaussian slabs (v4), counts-only all-to-all + "
-                         "sparse tie pass (v3), all-to-all of both planes (v2) or all-reduce of the histogram (v1)")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "pipelined", "sparse", "a2a", "allreduce"],
+                    help="multi-GPU protocol: all-gather of the packed maps + Gaussian slabs (v4), the same with the all-gather "
+                         "overlapped with the hand-over (GatherPipeline), counts-only all-to-all + sparse tie pass (v3), "
+                         "all-to-all of both planes (v2) or all-reduce of the histogram (v1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + several ranks on one GPU is a functional rehearsal only")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
@@ -214,14 +215,21 @@ def main():
 
     shard = None
     if world > 1:
-        shard = {"gather": pkg.dist.GpuGatherShard, "sparse": pkg.dist.GpuSparseShard, "a2a": pkg.dist.GpuSlabShard,
-                 "allreduce": pkg.dist.GpuVoteShard}[mode](ctx)
+        shard = {"gather": pkg.dist.GpuGatherShard, "pipelined": pkg.dist.GpuGatherShard, "sparse": pkg.dist.GpuSparseShard,
+                 "a2a": pkg.dist.GpuSlabShard, "allreduce": pkg.dist.GpuVoteShard}[mode](ctx)
     exchange = {"gather": pkg.dist.exchange_labels_gather, "sparse": pkg.dist.exchange_labels_sparse,
                 "a2a": pkg.dist.exchange_labels_a2a, "allreduce": pkg.dist.exchange_labels}.get(mode)
 
     def step():
         """The metric's span: first vote_view submit -> labels on the host."""
         ctx.vote_begin(args.classes, first, total_views)
+        if mode == "pipelined":
+            pipe = pkg.dist.GatherPipeline(shard, total_views)
+            for v in range(V):
+                ctx.vote_view(cam_structs[v], host_segs[v])
+                pipe.after_view()
+            pipe.finish(out=labels_buf)
+            return
         for v in range(V):
             ctx.vote_view(cam_structs[v], host_segs[v])
         if world == 1:
@@ -255,15 +263,16 @@ def main():
     value = n * total_views / (elapsed / args.steps)
     labels_main = labels_buf.copy()
     labels_check = None
-    if mode == "gather":
+    if mode in ("gather", "pipelined"):
         # after the import every rank holds every view: a plain single-GPU vote of ALL Gaussians on this rank must give
         # the labels the exchange assembled from the ranks' slabs (rank-local, no collective)
         labels_check = bool(np.array_equal(ctx.vote_finalize(), labels_main))
 
     # ---- dominant kernel: HIP-event time on the ctx stream over the timed region, algorithmic bytes / time -----------
-    kname = {None: "vote_fused_labels", "gather": "vote_fused_labels", "sparse": "vote_fused_counts"}.get(mode, "vote_fused_planes")
-    n_slab = n if mode != "gather" else (n + world - 1) // world
-    V_kernel = total_views if mode in (None, "gather") else V
+    kname = {None: "vote_fused_labels", "gather": "vote_fused_labels", "pipelined": "vote_fused_labels",
+             "sparse": "vote_fused_counts"}.get(mode, "vote_fused_planes")
+    n_slab = n if mode not in ("gather", "pipelined") else (n + world - 1) // world
+    V_kernel = total_views if mode in (None, "gather", "pipelined") else V
     roofline = None
     kernels_ms = None
     vis_frac = None
@@ -422,8 +431,9 @@ def main():
                        "gaussians": n, "views_total": total_views, "views_this_rank": V, "width": W, "height": H,
                        "classes": args.classes,
                        "seg_maps": f"Voronoi, 400 sites, evaluated on a {args.seg_cell}-px grid" + (" (pixel-accurate boundaries)" if args.seg_cell == 1 else ""),
-                       "parallelism": f"views sharded x{world}" + (", Gaussians sharded for the vote" if mode == "gather" else ""),
+                       "parallelism": f"views sharded x{world}" + (", Gaussians sharded for the vote" if mode in ("gather", "pipelined") else ""),
                        "exchange": {None: None, "gather": "all_gather(packed u8 maps) + per-rank Gaussian slab vote + all_gather(labels)",
+                                    "pipelined": "chunked all_gather(packed u8 maps) overlapped with the hand-over + per-rank Gaussian slab vote + all_gather(labels)",
                                     "sparse": "all_to_all(counts) + sparse tie pass + all_gather(labels)",
                                     "a2a": "all_to_all + slab arg-max + all_gather(labels)",
                                     "allreduce": "all_reduce(SUM) of the histogram + all_reduce(MAX) of tie keys"}[mode],

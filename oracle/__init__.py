@@ -476,6 +476,9 @@ class NumpyGatherShard:
     def export(self):
         return self._blobs, self._pool.size
 
+    def staged(self):
+        return len(self._blobs), self._pool.size
+
     def pool(self, chunk):
         out = np.zeros(chunk, np.uint8)
         out[:self._pool.size] = self._pool

@@ -831,6 +831,28 @@ for name, shard_cls, fn, a2a in (("gather", pkg.dist.GpuGatherShard, pkg.dist.ex
         got = fn(shard_cls(ctx), out=out)
         ok[f"{name}{rep}"] = bool(got is out and np.array_equal(out, want))
     ctx.close()
+# the pipelined gather: chunk all_gathers issued (async) between the hand-over calls, on the ctx stream
+ctx = pkg.Context(0)
+ctx.upload_positions(pos)
+for rep, chunks in enumerate((4, 1, 9, 3)):
+    ctx.vote_begin(12, 0, V)
+    pipe = pkg.dist.GatherPipeline(pkg.dist.GpuGatherShard(ctx), V, chunks=chunks)
+    for k, (cam, seg) in enumerate(zip(cams, segs)):
+        ctx.vote_view(cam, torch.from_numpy(seg).cuda() if (k + rep) % 2 else seg)
+        pipe.after_view()
+    out = np.empty(n, np.int32)
+    got = pipe.finish(out=out)
+    ok[f"pipeline{chunks}"] = bool(got is out and np.array_equal(out, want) and pipe.stride > 0 and pipe.next_chunk == pipe.C)
+# ... and its fallback when the maps are not of one geometry
+ctx.vote_begin(12, 0, V)
+pipe = pkg.dist.GatherPipeline(pkg.dist.GpuGatherShard(ctx), V)
+small = [s[::2, ::2].copy() if k == 4 else s for k, s in enumerate(segs)]
+want_small = oracle.assign_labels(pos, cams, small, [(W, H)] * V, threads=0)
+for cam, seg in zip(cams, small):
+    ctx.vote_view(cam, seg, (W, H))
+    pipe.after_view()
+ok["pipeline_fallback"] = bool(np.array_equal(pipe.finish(), want_small))
+ctx.close()
 dist.barrier(); torch.cuda.synchronize()
 dist.destroy_process_group()
 print("RESULT", ok)
