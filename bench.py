@@ -10,8 +10,9 @@ resident (PLY parsing is outside the metric).  Workload = BASELINE.json configs[
 150 classes (+ label -1), Voronoi maps with pixel-accurate boundaries.
 
 With --gpus N the SAME 200 views are sharded over the ranks (BASELINE configs[3]; strong scaling): every rank ingests
-its block of views, the packed maps are all-gathered, every rank votes its slab of the Gaussians, the labels are
-all-gathered (protocol v4, dist.exchange_labels_gather).  --weak-views V gives every rank V views instead.
+its block of views, the packed maps are all-gathered (chunk by chunk, overlapped with the hand-over: dist.GatherPipeline),
+every rank votes its slab of the Gaussians, the labels are all-gathered (protocol v4).  --weak-views V gives every rank V
+views instead.
 
 Side numbers at N=1 (never `value`): the same run with the int32 maps already resident in HBM (`resident_value`), and
 the vote kernel alone over maps already packed in HBM (`kernel_resident_value`, round 1's headline).
@@ -56,10 +57,10 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=3_000_000, help="Gaussians in the all-core CPU-baseline sample (0 = skip)")
     ap.add_argument("--render-views", type=int, default=4, help="rasterizer leg on rank 0 at N=1: views to render (0 = skip)")
     ap.add_argument("--render-splats", type=int, default=3_000_000)
-    ap.add_argument("--exchange", default="gather", choices=["gather", "pipelined", "sparse", "a2a", "allreduce"],
-                    help="multi-GPU protocol: all-gather of the packed maps + Gaussian slabs (v4), the same with the all-gather "
-                         "overlapped with the hand-over (GatherPipeline), counts-only all-to-all + sparse tie pass (v3), "
-                         "all-to-all of both planes (v2) or all-reduce of the histogram (v1)")
+    ap.add_argument("--exchange", default="pipelined", choices=["pipelined", "gather", "sparse", "a2a", "allreduce"],
+                    help="multi-GPU protocol: all-gather of the packed maps + Gaussian slabs (v4) with the all-gather overlapped "
+                         "with the hand-over (GatherPipeline, default) or in one piece (gather), counts-only all-to-all + sparse "
+                         "tie pass (v3), all-to-all of both planes (v2) or all-reduce of the histogram (v1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend; gloo + several ranks on one GPU is a functional rehearsal only")
     ap.add_argument("--opt", action="append", default=[], help="library tuning option name=value (gsx_set_option)")
