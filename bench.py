@@ -417,7 +417,11 @@ def main():
         render = render_leg(pkg, ctx, args, W, H)
 
     if rank == 0:
-        cfg = 2 if world == 1 else 3
+        shape = (n, total_views, W, H, args.classes)
+        cfg = {(3_000_000, 200, 1920, 1080, 150): "BASELINE configs[2]" if world == 1 else f"BASELINE configs[3]: the 200 views sharded over {world} GPUs",
+               (500_000, 16, 1280, 720, 150): "BASELINE configs[1]" + ("" if world == 1 else f" sharded over {world} GPUs"),
+               (10_000_000, 1000, 3840, 2160, 150): "BASELINE configs[4]" + (" on ONE GPU" if world == 1 else f": the 1000 views sharded over {world} GPUs")
+               }.get(shape, "not a BASELINE config (custom shape)")
         out = {
             "metric": "Gaussians·views/sec labelled (3M G, 1080p), majority vote; first vote_view submit -> labels on the host",
             "value": round(value, 1), "unit": "Gaussian·views/s", "n_gpus": world, "steps": args.steps,
@@ -425,8 +429,7 @@ def main():
             "scaling": "weak" if weak else "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"{n} Gaussians x {total_views} views in total @{W}x{H}, {args.classes} classes + (-1), "
-                                    + (f"weak scaling: {args.weak_views} views per GPU (not a BASELINE config)" if weak else
-                                       f"BASELINE configs[{cfg}]" + ("" if world == 1 else f": the 200 views sharded over {world} GPUs"))),
+                                    + (f"weak scaling: {args.weak_views} views per GPU (not a BASELINE config)" if weak else cfg)),
                        "timed_span": "gsx_vote_begin + one gsx_vote_view per view (host int32 map, pageable) + vote + arg-max + labels D2H "
                                      "into a host array (SURVEY 8d); positions resident",
                        "gaussians": n, "views_total": total_views, "views_this_rank": V, "width": W, "height": H,
