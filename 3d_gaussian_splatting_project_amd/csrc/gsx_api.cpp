@@ -211,6 +211,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
 int gsx_synchronize(gsx_ctx* ctx) {
     CTX_OR_FAIL(ctx);
     GSX_HIP(c, hipSetDevice(c->device));
+    {
+        const int rc = gsx::vote_flush_pending(c);
+        if (rc) return rc;
+    }
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     return GSX_OK;
 }
@@ -407,6 +411,10 @@ int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int
 int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes) {
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_export(c, reserve_bytes, blobs_out, pool_dev, pool_bytes); });
+}
+int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return (c && c->vote_begun && !c->pool_base) ? (int64_t)((c->seg_used + 255) / 256 * 256) : 0;
 }
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes) {

@@ -107,6 +107,8 @@ struct PinSlot {
     bool busy = false;
 };
 static constexpr int kPinSlots = 4;
+static constexpr int kDmaBatch = 4;    // packed host maps per H2D copy (one hipMemcpyAsync + event record costs ~6 us of host time)
+static constexpr int kDmaGroups = 3;   // ring = kDmaGroups groups of kDmaBatch slots: one filling, one or two in flight
 static constexpr int kLabelChunks = 4;
 static constexpr int kNoBadView = 0x7f7f7f7f;  // errflag value meaning "every device-side map was in range"
 
@@ -169,8 +171,17 @@ struct Ctx {
     int opt_host_threads = 0;  // 0: default_host_threads()
     int opt_host_pack = 1;     // 1: host maps are narrowed to u8 by the workers (2.2 MB/map over PCIe); 0: raw copy + GPU pack kernel (8.3 MB/map)
     DevBuf dstage[kPinSlots];  // host_pack = 0: device-side landing zone of the raw map of each ring slot
-    PinSlot ring[kPinSlots];
+    PinSlot ring[kPinSlots];   // host_pack = 0: raw maps
     int ring_next = 0;
+    // host_pack = 1: ONE pinned buffer of kDmaGroups * kDmaBatch slots, a slot = the pool stride of the map geometry, so that
+    // consecutive packed maps are consecutive both here and in the pool and a whole group goes up in one DMA
+    void* hring = nullptr;
+    size_t hring_bytes = 0, hring_slot = 0;
+    hipEvent_t hring_ev[kDmaGroups] = {nullptr, nullptr, nullptr};
+    bool hring_busy[kDmaGroups] = {false, false, false};
+    int hring_next = 0;
+    int pend_first = 0, pend_count = 0;  // packed maps of the filling group whose DMA has not been queued yet
+    size_t pend_dst = 0;
     void* h_labels = nullptr;  // pinned: n int32 labels + one int (the error flag) land here before the caller's array
     size_t h_labels_cap = 0;
     hipEvent_t h_ev[kLabelChunks] = {nullptr, nullptr, nullptr, nullptr};
@@ -238,6 +249,7 @@ int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* p
                 const void* pool_all_dev, int64_t pool_all_bytes);
 int vote_slab_labels(Ctx* c, int slab, int slabs, int64_t* slab_size);
 int host_threads(Ctx* c);
+int vote_flush_pending(Ctx* c);  // queue the DMA of packed host maps that are still waiting for their group to fill
 void vote_release_host(Ctx* c);  // pinned buffers, events, worker pool (gsx_destroy)
 int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes, int tiled, int coarse, int threads,
                     uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off, int32_t* bad);

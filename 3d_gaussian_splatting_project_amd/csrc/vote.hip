@@ -1035,6 +1035,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     if (c->sn == 0) c->sn = 256;
     c->n_pad = c->sn * c->slabs;
     c->views.clear();
+    c->pend_count = 0;  // packed maps of an abandoned run that never went up: forgotten with it
     c->views_dirty = true;
     c->pool_base = nullptr;
     c->seg_used = 0;
@@ -1051,6 +1052,10 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
 
 static int pool_reserve(Ctx* c, size_t need) {
     if (need <= c->segpool.cap) return GSX_OK;
+    {
+        const int rcf = vote_flush_pending(c);  // the pool is about to move: maps still waiting in the pinned ring go up first
+        if (rcf) return rcf;
+    }
     size_t cap = c->segpool.cap ? c->segpool.cap : ((size_t)64 << 20);
     while (cap < need) cap *= 2;
     void* np = nullptr;
@@ -1132,6 +1137,49 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
     MapLayout L;
     int rc = view_prologue(c, "vote_view", cam, seg, 1, seg_dtype, seg_w, seg_h, img_w, img_h, L);
     if (rc) return rc;
+    if (c->opt_host_pack) {
+        const size_t stride = (L.map_bytes + 255) / 256 * 256;
+        constexpr int kSlots = kDmaBatch * kDmaGroups;
+        if (c->hring_slot != stride || !c->hring) {  // first map, or a new geometry: re-lay the ring
+            if ((rc = vote_flush_pending(c))) return rc;
+            for (int g = 0; g < kDmaGroups; ++g) {
+                if (c->hring_busy[g]) GSX_HIP(c, hipEventSynchronize(c->hring_ev[g]));
+                c->hring_busy[g] = false;
+                if (!c->hring_ev[g]) GSX_HIP(c, hipEventCreateWithFlags(&c->hring_ev[g], hipEventDisableTiming));
+            }
+            if (c->hring_bytes < stride * kSlots) {
+                if (c->hring) GSX_HIP(c, hipHostFree(c->hring));
+                c->hring = nullptr;
+                c->hring_bytes = 0;
+                GSX_HIP(c, hipHostMalloc(&c->hring, stride * kSlots, hipHostMallocDefault));
+                c->hring_bytes = stride * kSlots;
+            }
+            std::memset(c->hring, 0, stride * kSlots);  // the bytes between a map's end and its stride travel too
+            c->hring_slot = stride;
+            c->hring_next = 0;
+        }
+        const int s = c->hring_next, g = s / kDmaBatch;
+        if (s % kDmaBatch == 0 && c->hring_busy[g]) {  // the group's previous DMA must have left the buffer
+            GSX_HIP(c, hipEventSynchronize(c->hring_ev[g]));
+            c->hring_busy[g] = false;
+        }
+        uint8_t* slot = static_cast<uint8_t*>(c->hring) + (size_t)s * stride;
+        if (host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, slot))
+            return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
+        const size_t off = (c->seg_used + 255) / 256 * 256;
+        if (c->pend_count && off != c->pend_dst + (size_t)c->pend_count * stride) {  // the pool moved on (device maps in between)
+            if ((rc = vote_flush_pending(c))) return rc;
+        }
+        if (!c->pend_count) {
+            c->pend_first = s;
+            c->pend_dst = off;
+        }
+        ++c->pend_count;
+        push_view(c, cam, L, off, img_w, img_h);
+        c->hring_next = (s + 1) % kSlots;
+        if (c->pend_count == kDmaBatch || c->hring_next % kDmaBatch == 0) return vote_flush_pending(c);
+        return GSX_OK;
+    }
     PinSlot& slot = c->ring[c->ring_next];
     if (slot.busy) {
         GSX_HIP(c, hipEventSynchronize(slot.ev));
@@ -1146,7 +1194,7 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
         slot.cap = cap;
     }
     if (!slot.ev) GSX_HIP(c, hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
-    if (!c->opt_host_pack) {
+    {
         // The alternative this library does NOT default to (kept for hosts short of cores, and as the A/B of DESIGN.md §3):
         // the raw map crosses PCIe (8.3 MB instead of 2.2 MB per 1080p int32 map) and the fused kernel packs it on the GPU.
         // The range check is then the device-side one (reported with the labels).
@@ -1180,15 +1228,7 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
         push_view(c, cam, L, off, img_w, img_h);
         return GSX_OK;
     }
-    if (host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(slot.p)))
-        return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
-    const size_t off = (c->seg_used + 255) / 256 * 256;
-    GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + off, slot.p, L.map_bytes, hipMemcpyHostToDevice, c->stream));
-    GSX_HIP(c, hipEventRecord(slot.ev, c->stream));
-    slot.busy = true;
-    c->ring_next = (c->ring_next + 1) % kPinSlots;
-    push_view(c, cam, L, off, img_w, img_h);
-    return GSX_OK;
+    return GSX_OK;  // unreachable: both hand-over paths return above
 }
 
 static void launch_pack(Ctx* c, const PackArgs& a, int jobs, int seg_dtype, bool vec, long long cells) {
@@ -1236,6 +1276,23 @@ int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* 
     return GSX_OK;
 }
 
+// One DMA for the packed maps that wait in the filling group of the pinned ring (up to kDmaBatch consecutive slots =
+// consecutive pool offsets).  Called when the group is full, and by everything that needs the maps on the device.
+int vote_flush_pending(Ctx* c) {
+    if (!c->pend_count) return GSX_OK;
+    const int g = c->pend_first / kDmaBatch;
+    const size_t bytes = (size_t)c->pend_count * c->hring_slot;
+    GSX_HIP(c, hipSetDevice(c->device));
+    GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + c->pend_dst, static_cast<uint8_t*>(c->hring) + (size_t)c->pend_first * c->hring_slot,
+                              bytes, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipEventRecord(c->hring_ev[g], c->stream));
+    c->hring_busy[g] = true;
+    c->pend_count = 0;
+    // a group that was flushed before it was full is closed: the next map starts the next group
+    c->hring_next = ((g + 1) % kDmaGroups) * kDmaBatch;
+    return GSX_OK;
+}
+
 int host_threads(Ctx* c) {
     Workers* w = host_workers(c);
     return w ? w->threads() : 1;
@@ -1248,6 +1305,14 @@ void vote_release_host(Ctx* c) {
         s = PinSlot{};
     }
     for (DevBuf& b : c->dstage) b.release();
+    for (hipEvent_t& e : c->hring_ev) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
+    if (c->hring) (void)hipHostFree(c->hring);
+    c->hring = nullptr;
+    c->hring_bytes = c->hring_slot = 0;
+    c->pend_count = 0;
     for (hipEvent_t& e : c->h_ev) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
@@ -1350,6 +1415,10 @@ void debug_cull_planes(const gsx_camera* cam, double* out) {
 // and wave), the culling planes are derived here.  Staged through pinned memory owned by the ctx and guarded by an
 // event, so nothing waits for the stream: the maps that vote_view queued keep flowing while this is prepared.
 static int sync_views(Ctx* c) {
+    {
+        const int rcf = vote_flush_pending(c);  // every consumer of the views comes through here
+        if (rcf) return rcf;
+    }
     if (!c->views_dirty) return GSX_OK;
     const size_t nv = c->views.size();
     const size_t bytes = sizeof(ViewDesc) * (nv ? nv : 1);
@@ -1753,6 +1822,10 @@ int vote_export(Ctx* c, int64_t reserve_bytes, void* blobs_out, void** pool_dev,
     if (c->pool_base) return fail(c, GSX_E_STATE, "vote_export after vote_import");
     GSX_HIP(c, hipSetDevice(c->device));
     if (reserve_bytes < 0) return fail(c, GSX_E_INVALID, "vote_export: negative size");
+    {
+        const int rcf = vote_flush_pending(c);  // the caller is about to read the pool (all-gather)
+        if (rcf) return rcf;
+    }
     const size_t used = (c->seg_used + 255) / 256 * 256;
     int rc = pool_reserve(c, std::max<size_t>(std::max<size_t>((size_t)reserve_bytes, used), 256));
     if (rc) return rc;

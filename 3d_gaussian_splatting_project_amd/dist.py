@@ -344,9 +344,12 @@ class GpuGatherShard(_GpuShard):
         return self._pool_all[:nbytes]
 
     def staged(self):
-        """(views staged so far, pool bytes in use)"""
-        _, used, _ = self.ctx.vote_export(0, blobs=False)
-        return self.ctx.vote_num_views(), used
+        """(views staged so far, pool bytes in use) - no stream work"""
+        return self.ctx.vote_num_views(), self.ctx.vote_pool_bytes()
+
+    def flush(self):
+        """every staged map's DMA is queued on the ctx stream (packed host maps go up in groups)"""
+        self.ctx.vote_export(0, blobs=False)
 
     def device(self):
         return torch.device("cuda", self.ctx.device)
@@ -389,6 +392,9 @@ class HostGatherShard:
 
     def staged(self):
         return self.shard.staged()
+
+    def flush(self):
+        pass
 
     def device(self):
         return torch.device("cpu")
@@ -498,6 +504,7 @@ class GatherPipeline:
     def _issue(self, j):
         if self.stride:
             cb = self.m * self.stride
+            self.shard.flush()
             with _stream_of(self.shard):
                 w = _all_gather_into(self.pool_all[j * self.world * cb:(j + 1) * self.world * cb], self.pool_src[j * cb:(j + 1) * cb],
                                      self.group, async_op=True)

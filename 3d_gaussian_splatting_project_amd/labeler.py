@@ -266,6 +266,9 @@ class Context:
                                         C.byref(used)), self.h)
         return ptr.value, int(used.value), b
 
+    def vote_pool_bytes(self):
+        return int(self._lib.gsx_vote_pool_bytes(self.h))
+
     def vote_import(self, part_views, part_offsets, blobs, pool_all_ptr, pool_all_bytes):
         pv = np.ascontiguousarray(part_views, np.int32)
         po = np.ascontiguousarray(part_offsets, np.int64)

@@ -158,7 +158,8 @@ int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t 
 /* seg: HOST pointer, seg_h x seg_w row-major.  img_w,img_h: the PIL image size (dls.py:261-263).
  * The map is read during the call (worker threads narrow it to the u8 on-device form inside pinned memory and
  * check the label range: GSX_E_RANGE fails THIS call and stages nothing); the DMA into the pool is asynchronous
- * and nothing is synchronised: 200 calls cost the host pass over the maps, ~2.2 MB of PCIe traffic per 1080p map.
+ * (one copy per group of 4 consecutive maps: an enqueue costs ~6 us of host time) and nothing is synchronised: 200 calls
+ * cost the host pass over the maps, ~2.2 MB of PCIe traffic per 1080p map.
  * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool.
  * Option "host_pack" = 0 selects the alternative hand-over: the workers only copy the raw map into pinned memory, the raw
  * bytes cross PCIe (4x as many for int32) and the fused kernel of gsx_vote_view_device packs them; the range check is
@@ -251,6 +252,9 @@ int gsx_vote_labels_from_sorted(gsx_ctx* ctx, const void* sorted_labels_dev, int
  * blobs_out (may be NULL): gsx_vote_num_views() * GSX_VIEW_BLOB_BYTES bytes on the host.  *pool_dev: the pool,
  * valid until the next gsx_vote_view* / gsx_vote_begin; *pool_bytes: bytes in use (a multiple of 256). */
 int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes);
+/* bytes of this rank's pool in use (what gsx_vote_export reports), without touching the stream: host maps that are packed
+ * but whose grouped DMA has not been queued yet are counted; gsx_vote_export queues them */
+int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx);
 /* part r contributed part_views[r] views (blobs in part order) whose maps start at byte part_offsets[r] of
  * pool_all_dev (pool_all_bytes long; caller-owned, must stay alive and unchanged until the labels have been fetched).
  * Replaces the views staged so far; global view order = part order.  Blobs are validated against the pool size. */
