@@ -468,8 +468,14 @@ class GatherPipeline:
     If the maps are not of ONE geometry (strides differ between ranks, or a rank finds its own pool irregular at the end),
     every rank learns it from gathered data and all fall back to the plain gather of exchange_labels_gather."""
 
-    def __init__(self, shard, total_views, group=None, chunks=4):
+    def __init__(self, shard, total_views, group=None, chunks=4, assume_uniform=False):
+        """assume_uniform: the caller guarantees that EVERY view of EVERY rank has the same map geometry (a capture from one
+        camera model).  The agreement collective and its host wait are then skipped - provided every rank owns at least
+        one view, which all ranks can tell from (total_views, world).  A rank that finds its own pool irregular still
+        reports it in the header and all ranks fall back together; a geometry that differs BETWEEN ranks would however make
+        the chunk collectives disagree in size, which is why this is a promise and not the default."""
         self.shard, self.group, self.total = shard, group, int(total_views)
+        self.assume_uniform = bool(assume_uniform)
         on = dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
@@ -488,13 +494,16 @@ class GatherPipeline:
     def _agree(self):
         nv, used = self.shard.staged()
         mine = used // nv if nv and used % nv == 0 else (-1 if nv == 0 else 0)   # -1: no view yet (no opinion); 0: irregular
-        dev = self.shard.device()
-        t = torch.tensor([mine], dtype=torch.int64, device=dev)
-        alls = torch.empty(self.world, dtype=torch.int64, device=dev)
-        _all_gather_into(alls, t, self.group)
-        vals = [int(v) for v in alls.cpu().tolist()]
-        have = [v for v in vals if v >= 0]
-        self.stride = have[0] if have and all(v == have[0] and v > 0 and v % 256 == 0 for v in have) else 0
+        if self.assume_uniform and min(self.n) >= 1 and nv:
+            self.stride = mine if mine > 0 and mine % 256 == 0 else 0             # every rank derives the same number locally
+        else:
+            dev = self.shard.device()
+            t = torch.tensor([mine], dtype=torch.int64, device=dev)
+            alls = torch.empty(self.world, dtype=torch.int64, device=dev)
+            _all_gather_into(alls, t, self.group)
+            vals = [int(v) for v in alls.cpu().tolist()]
+            have = [v for v in vals if v >= 0]
+            self.stride = have[0] if have and all(v == have[0] and v > 0 and v % 256 == 0 for v in have) else 0
         if self.stride:
             with _stream_of(self.shard):
                 need = self.C * self.m * self.stride

@@ -182,8 +182,15 @@ def main():
     device = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(device)
     bound = None if args.no_numa_bind else pkg.bind_to_gpu_numa_node(device)
-    if world > 1:
+    # GSX_DIST_FORCE_COLLECTIVES=1 with one GPU: rehearse the N > 1 code path (process group, exchange protocol, fences, the
+    # max-over-ranks reduction) through real RCCL with a one-rank group; the JSON line says so
+    rehearsal = world == 1 and os.environ.get("GSX_DIST_FORCE_COLLECTIVES") == "1"
+    if world > 1 or rehearsal:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        if rehearsal:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -205,7 +212,8 @@ def main():
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    mode = args.exchange if world > 1 else None
+    mode = args.exchange if (world > 1 or rehearsal) else None
+    multi = mode is not None
     if mode in ("a2a", "sparse"):
         if max(b - a for a, b in (pkg.dist.view_range(total_views, r, world) for r in range(world))) > 255:
             raise SystemExit("--exchange a2a/sparse keep 8-bit per-rank counters: at most 255 views per rank")
@@ -215,7 +223,7 @@ def main():
     labels_buf = np.empty(n, np.int32)
 
     shard = None
-    if world > 1:
+    if multi:
         shard = {"gather": pkg.dist.GpuGatherShard, "pipelined": pkg.dist.GpuGatherShard, "sparse": pkg.dist.GpuSparseShard,
                  "a2a": pkg.dist.GpuSlabShard, "allreduce": pkg.dist.GpuVoteShard}[mode](ctx)
     exchange = {"gather": pkg.dist.exchange_labels_gather, "sparse": pkg.dist.exchange_labels_sparse,
@@ -225,7 +233,7 @@ def main():
         """The metric's span: first vote_view submit -> labels on the host."""
         ctx.vote_begin(args.classes, first, total_views)
         if mode == "pipelined":
-            pipe = pkg.dist.GatherPipeline(shard, total_views)
+            pipe = pkg.dist.GatherPipeline(shard, total_views, assume_uniform=True)   # one synthetic camera model
             for v in range(V):
                 ctx.vote_view(cam_structs[v], host_segs[v])
                 pipe.after_view()
@@ -233,7 +241,7 @@ def main():
             return
         for v in range(V):
             ctx.vote_view(cam_structs[v], host_segs[v])
-        if world == 1:
+        if not multi:
             ctx.vote_finalize(out=labels_buf)
         else:
             exchange(shard, out=labels_buf)
@@ -241,7 +249,7 @@ def main():
     def fence():
         ctx.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -256,7 +264,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -320,7 +328,7 @@ def main():
 
     # ---- side measurements at N=1: int32 maps resident in HBM; packed maps resident (kernel only) ------------------------
     side = {}
-    if world == 1 and rank == 0 and args.side_steps > 0:
+    if not multi and rank == 0 and args.side_steps > 0:
         S = args.side_steps
         dev_maps = torch.from_numpy(np.stack(host_segs)).cuda()          # (V, H, W) int32 in HBM
         torch.cuda.synchronize()
@@ -373,7 +381,7 @@ def main():
 
     # ---- CPU baseline: the oracle (C port of the reference loop) on bounded samples of the same workload ----------------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and not multi and args.cpu_sample > 0:
         import oracle
         sizes = [(W, H)] * V
         cams_cpu = cams_all[:V]
@@ -413,7 +421,7 @@ def main():
 
     # ---- rasterizer leg (reported beside the headline metric, never part of `value`) ---------------------
     render = None
-    if rank == 0 and world == 1 and args.render_views > 0:
+    if rank == 0 and not multi and args.render_views > 0:
         render = render_leg(pkg, ctx, args, W, H)
 
     if rank == 0:
@@ -444,6 +452,7 @@ def main():
                        "camera_convention": "w2c (labeler's R@(x-p) looks at the scene)",
                        "visible_fraction": None if vis_frac is None else round(vis_frac, 4),
                        "wave_views_culled_fraction": round(culled_frac, 4),
+                       "rehearsal": "N > 1 code path with a ONE-rank RCCL group (GSX_DIST_FORCE_COLLECTIVES=1)" if rehearsal else None,
                        "bound_to_gpu_numa_node": None if bound is None else f"{len(bound)} CPUs",
                        "setup_seconds": round(setup_s, 1),
                        "exchanged_labels_equal_single_gpu_vote": labels_check},
@@ -456,7 +465,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

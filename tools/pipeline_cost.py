@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""GPU box: host-side cost of the pipelined gather, one-rank RCCL group (collectives run for real on this rank alone)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29699", GSX_DIST_FORCE_COLLECTIVES="1")
+pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+scene = pkg.scene
+torch.cuda.set_device(0)
+pkg.bind_to_gpu_numa_node(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n, V, W, H = 3_000_000, 25, 1920, 1080          # one rank's share of configs[3] at 8 GPUs
+pos = scene.make_positions(n, scene.BASE_SEED + 3)
+cams = [pkg.Camera.from_dict(c) for c in scene.make_cameras(200, W, H, convention="w2c")[:V]]
+segs = [scene.make_segmap(H, W, 150, 3000 + v, cell=4) for v in range(V)]
+ctx = pkg.Context(0)
+ctx.upload_positions(pos)
+out = np.empty(n, np.int32)
+shard = pkg.dist.GpuGatherShard(ctx)
+def run(mode, chunks=4):
+    ctx.vote_begin(150, 0, V)
+    if mode == "pipe":
+        p = pkg.dist.GatherPipeline(shard, V, chunks=chunks, assume_uniform=True)
+        for v in range(V):
+            ctx.vote_view(cams[v], segs[v]); p.after_view()
+        p.finish(out=out)
+    elif mode == "gather":
+        for v in range(V):
+            ctx.vote_view(cams[v], segs[v])
+        pkg.dist.exchange_labels_gather(shard, out=out, cap_views=V)
+    else:
+        for v in range(V):
+            ctx.vote_view(cams[v], segs[v])
+        ctx.vote_finalize(out=out)
+for mode, ch in (("single", 0), ("gather", 0), ("pipe", 1), ("pipe", 2), ("pipe", 4), ("pipe", 8)):
+    for _ in range(3): run(mode, ch)
+    t0 = time.perf_counter()
+    for _ in range(20): run(mode, ch)
+    print(f"{mode:7s} chunks={ch}: {(time.perf_counter()-t0)/20*1e3:.3f} ms per 25-view run")
+dist.destroy_process_group()
