@@ -156,7 +156,7 @@ def test_gather_exchange_equals_reference_labels(case_idx, world, product_packer
     assert all(ok for _, ok, _ in res), res
 
 
-def _worker_pipeline(rank, world, port, case_idx, chunks, q):
+def _worker_pipeline(rank, world, port, case_idx, chunks, q, uniform=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -167,7 +167,7 @@ def _worker_pipeline(rank, world, port, case_idx, chunks, q):
         name, pos, cams, segs, sizes, labels = golden_assign_cases()[case_idx]
         lo, hi = pkg.dist.view_range(len(cams), rank, world)
         shard = oracle.NumpyGatherShard(pos, cams[lo:hi], segs[lo:hi], sizes[lo:hi], 150)
-        pipe = pkg.dist.GatherPipeline(pkg.dist.HostGatherShard(shard), len(cams), chunks=chunks)
+        pipe = pkg.dist.GatherPipeline(pkg.dist.HostGatherShard(shard), len(cams), chunks=chunks, assume_uniform=uniform)
         for _ in range(hi - lo):
             pipe.after_view()
         got = pipe.finish()
@@ -198,6 +198,25 @@ def test_pipelined_gather_equals_reference_labels(case_idx, world, chunks):
         assert strides == {0}                     # mixed geometries: the fallback
     elif case_idx != 0:
         assert strides != {0}                     # uniform maps: really pipelined
+
+
+@pytest.mark.parametrize("case_idx,world", [(2, 2), (3, 3), (0, 3)])
+def test_pipelined_gather_without_the_agreement_collective(case_idx, world):
+    """assume_uniform=True: every rank derives the stride from its own first map and the agreement all_gather is skipped -
+    unless some rank owns no view (case 0: one view, three ranks), which every rank can tell from (total, world) alone,
+    so all of them run the agreement after all and the collective sequences still match."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 39500 + (os.getpid() + case_idx * 23 + world) % 2000
+    procs = [ctx.Process(target=_worker_pipeline, args=(r, world, port, case_idx, 3, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert len({info[1] for _, _, info in res}) == 1
 
 
 def test_view_range_is_contiguous_and_ordered():
