@@ -494,7 +494,9 @@ class GatherPipeline:
     def _agree(self):
         nv, used = self.shard.staged()
         mine = used // nv if nv and used % nv == 0 else (-1 if nv == 0 else 0)   # -1: no view yet (no opinion); 0: irregular
-        if self.assume_uniform and min(self.n) >= 1 and nv:
+        if self.assume_uniform and min(self.n) >= 1:
+            if not nv:  # the peers are about to join chunk collectives this rank cannot size: fail loudly, not silently out of step
+                raise RuntimeError(f"GatherPipeline: rank {self.rank} staged no view, but view_range gives it {self.n[self.rank]}")
             self.stride = mine if mine > 0 and mine % 256 == 0 else 0             # every rank derives the same number locally
         else:
             dev = self.shard.device()
