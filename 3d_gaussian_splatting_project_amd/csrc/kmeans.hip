@@ -8,8 +8,8 @@
 //   update   (k_means.py:125-128)  numpy's float32 mean over axis 0 adds the member rows IN INDEX ORDER into a float32
 //            accumulator.  Floating-point addition does not reassociate, so the sum is made the same way: a stable
 //            radix sort of the row indices by label puts every cluster's members in index order, and one wave per
-//            workgroup per cluster adds them one after the other (fifteen waves stage the rows through an LDS ring,
-//            six lanes - one per dimension - do the adds).  The division by float32(count) and the convergence test (:132-136) run on
+//            workgroup per cluster adds them one after the other (fifteen waves stage the rows through a transposed
+//            LDS ring, six lanes - one per dimension - do the adds, four members per LDS read).  The division by float32(count) and the convergence test (:132-136) run on
 //            the host.
 //
 // Data layout in HBM: rows float[n][6] (24 B, AoS as in the PLY), labels u32[n], order u32[n] (row indices grouped by
@@ -64,27 +64,41 @@ __global__ __launch_bounds__(kKmBlock) void kmeans_assign_kernel(const float* __
 }
 
 // One workgroup per cluster: sums[c][d] = ((row[o0][d] + row[o1][d]) + row[o2][d]) + ... in float32, members in
-// index order.  The chain of additions is serial by definition, so the kernel only makes sure it never waits for
-// memory: waves 1..15 fetch the next 960 member rows into one half of an LDS ring while lanes 0..5 of wave 0 (one per
-// dimension) add the previous 960 from the other half.
+// index order.  The chain of additions is serial by definition (it is the kernel's floor: one dependent v_add_f32 per
+// member), so everything else is kept out of its way: waves 1..15 fetch the next kSumRows member rows into one half of
+// an LDS ring, TRANSPOSED to [dimension][row], while lanes 0..5 of wave 0 (one per dimension) add the previous kSumRows
+// from the other half - four members per ds_read_b128, sixteen in flight before their sixteen ordered additions.
 static constexpr int kSumThreads = 1024;
-static constexpr int kSumRows = kSumThreads - 64;
+static constexpr int kSumLoaders = kSumThreads - 64;
+static constexpr int kSumPerLoader = 2;
+static constexpr int kSumRows = kSumLoaders * kSumPerLoader;  // 1920 rows per stage: 2 x 6 x 1920 floats = 90 KB of LDS
 __global__ __launch_bounds__(kSumThreads) void kmeans_sum_kernel(const float* __restrict__ rows,
                                                                  const uint32_t* __restrict__ order,
                                                                  const uint32_t* __restrict__ offsets /*[k+1]*/,
                                                                  float* __restrict__ sums) {
-    __shared__ float stage[2][kSumRows][6];
+    extern __shared__ float4 stage_raw[];  // [2][6][kSumRows] floats, 16-byte aligned
+    float* stage = reinterpret_cast<float*>(stage_raw);
     const int c = blockIdx.x, tid = threadIdx.x;
     const uint32_t beg = offsets[c], end = offsets[c + 1];
     float acc = 0.0f;
     bool first = true;  // numpy's reduction starts FROM the first row, not from +0.0 (the sign of a zero sum)
     auto load = [&](uint32_t t0, int buf) {  // loader waves only
-        const uint32_t t = t0 + (uint32_t)(tid - 64);
-        if (tid >= 64 && t < end) {
-            const float2* r = reinterpret_cast<const float2*>(rows + (size_t)order[t] * 6);
-            const float2 a = r[0], b = r[1], d = r[2];
-            float* s = stage[buf][tid - 64];
-            s[0] = a.x, s[1] = a.y, s[2] = b.x, s[3] = b.y, s[4] = d.x, s[5] = d.y;
+        if (tid < 64) return;
+        float* sb = stage + (size_t)buf * 6 * kSumRows;
+#pragma unroll
+        for (int q = 0; q < kSumPerLoader; ++q) {
+            const int local = (tid - 64) + q * kSumLoaders;
+            const uint32_t t = t0 + (uint32_t)local;
+            if (t < end) {
+                const float2* r = reinterpret_cast<const float2*>(rows + (size_t)order[t] * 6);
+                const float2 a = r[0], b = r[1], d = r[2];
+                sb[0 * kSumRows + local] = a.x;
+                sb[1 * kSumRows + local] = a.y;
+                sb[2 * kSumRows + local] = b.x;
+                sb[3 * kSumRows + local] = b.y;
+                sb[4 * kSumRows + local] = d.x;
+                sb[5 * kSumRows + local] = d.y;
+            }
         }
     };
     int buf = 0;
@@ -93,21 +107,26 @@ __global__ __launch_bounds__(kSumThreads) void kmeans_sum_kernel(const float* __
         __syncthreads();                                  // stage[buf] is complete, stage[buf ^ 1] is free
         if (t0 + kSumRows < end) load(t0 + kSumRows, buf ^ 1);
         if (tid < 6) {
+            const float* col = stage + ((size_t)buf * 6 + tid) * kSumRows;  // my dimension of the staged members
             const int m = (int)min((uint32_t)kSumRows, end - t0);
             int j = 0;
             if (first && m > 0) {
-                acc = stage[buf][0][tid];
+                acc = col[0];
                 first = false;
                 j = 1;
             }
-            for (; j + 16 <= m; j += 16) {  // 16 LDS reads in flight, then the 16 additions in order
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = stage[buf][j + u][tid];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) acc = acc + v[u];
+            for (; j < m && (j & 3); ++j) acc = acc + col[j];  // up to a 16-byte boundary
+            for (; j + 16 <= m; j += 16) {                      // 4 x ds_read_b128 in flight, then the 16 additions in order
+                const float4 v0 = *reinterpret_cast<const float4*>(col + j);
+                const float4 v1 = *reinterpret_cast<const float4*>(col + j + 4);
+                const float4 v2 = *reinterpret_cast<const float4*>(col + j + 8);
+                const float4 v3 = *reinterpret_cast<const float4*>(col + j + 12);
+                acc = acc + v0.x; acc = acc + v0.y; acc = acc + v0.z; acc = acc + v0.w;
+                acc = acc + v1.x; acc = acc + v1.y; acc = acc + v1.z; acc = acc + v1.w;
+                acc = acc + v2.x; acc = acc + v2.y; acc = acc + v2.z; acc = acc + v2.w;
+                acc = acc + v3.x; acc = acc + v3.y; acc = acc + v3.z; acc = acc + v3.w;
             }
-            for (; j < m; ++j) acc = acc + stage[buf][j][tid];
+            for (; j < m; ++j) acc = acc + col[j];
         }
         buf ^= 1;
     }
@@ -167,6 +186,8 @@ int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, c
         GSX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_assign_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
+    GSX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kmeans_sum_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(float) * 2 * 6 * kSumRows)));
     int iters = 0, converged = 0;
     for (int it = 0; it < max_iter; ++it) {  // :113
         int rc = assign();
@@ -184,8 +205,8 @@ int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, c
         GSX_HIP(c, hipMemcpyAsync(offsets.p, ho.data(), sizeof(uint32_t) * (k + 1), hipMemcpyHostToDevice, c->stream));
         {
             ProfScope ps(c, "kmeans_sum");
-            hipLaunchKernelGGL(kmeans_sum_kernel, dim3(k), dim3(kSumThreads), 0, c->stream, rows.as<float>(), order, offsets.as<uint32_t>(),
-                               sums.as<float>());
+            hipLaunchKernelGGL(kmeans_sum_kernel, dim3(k), dim3(kSumThreads), sizeof(float) * 2 * 6 * kSumRows, c->stream, rows.as<float>(), order,
+                               offsets.as<uint32_t>(), sums.as<float>());
             GSX_HIP(c, hipGetLastError());
         }
         GSX_HIP(c, hipMemcpyAsync(hs.data(), sums.p, sizeof(float) * 6 * k, hipMemcpyDeviceToHost, c->stream));
