@@ -12,7 +12,8 @@
  *   - host pointers are read/written during the call only; the library never keeps them.
  *   - device pointers returned by *_device() accessors stay valid until the next gsx_vote_begin /
  *     gsx_upload_* on the same ctx, and belong to the ctx.
- *   - one ctx = one GPU = one HIP stream; a ctx is used from one host thread at a time.
+ *   - one ctx = one GPU = one HIP stream (gsx_render_views adds a second, internal one); a ctx is used from one host
+ *     thread at a time; the library runs its own worker threads for host-side packing and the second render stream.
  *   - there is NO CPU fallback: without a gfx950 device gsx_create fails with GSX_E_HIP.
  */
 #ifndef GSX_H
