@@ -317,6 +317,13 @@ int gsx_vote_views_device(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, const
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_views_device(c, n, cams, segs_dev, seg_dtype, seg_w, seg_h, img_w, img_h); });
 }
+int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_parts) {
+    try {
+        return gsx::workers_stress(threads, runs, max_parts);
+    } catch (...) {
+        return -1;
+    }
+}
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad) {

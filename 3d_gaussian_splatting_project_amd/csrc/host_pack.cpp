@@ -509,4 +509,26 @@ void host_copy(Workers* pool, void* dst, const void* src, size_t bytes) {
     pool->run((int)((bytes + j.chunk - 1) / j.chunk), copy_part, &j);
 }
 
+struct StressJob {
+    std::atomic<int>* hits;
+};
+static void stress_part(void* arg, int part) { static_cast<StressJob*>(arg)->hits[part].fetch_add(1, std::memory_order_relaxed); }
+
+long long workers_stress(int threads, int runs, int max_parts) {
+    if (max_parts < 1) max_parts = 1;
+    Workers pool(threads);
+    std::vector<std::atomic<int>> hits((size_t)max_parts);
+    long long wrong = 0;
+    uint64_t state = 0x9e3779b97f4a7c15ull;
+    for (int r = 0; r < runs; ++r) {
+        state = state * 6364136223846793005ull + 1442695040888963407ull;
+        const int parts = 1 + (int)((state >> 33) % (uint64_t)max_parts);
+        for (int p = 0; p < max_parts; ++p) hits[(size_t)p].store(0, std::memory_order_relaxed);
+        StressJob j{hits.data()};
+        pool.run(parts, stress_part, &j);
+        for (int p = 0; p < max_parts; ++p) wrong += hits[(size_t)p].load(std::memory_order_relaxed) != (p < parts ? 1 : 0);
+    }
+    return wrong;
+}
+
 }  // namespace gsx

@@ -358,6 +358,9 @@ int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad);
+/* test hook, host only: `runs` fork-joins of pseudo-random size (1..max_parts parts) on ONE worker pool of `threads` threads;
+ * returns how many parts did not run exactly once (0 = the pool is sound), -1 if the pool could not be created */
+int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_parts);
 /* statistics: (wave of 64 Gaussians, view) pairs the vote kernels skipped through the wave culling since the context
  * was created or since the last call with reset != 0 */
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);

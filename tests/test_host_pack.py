@@ -95,3 +95,12 @@ def test_full_hd_map_many_threads():
     assert not bad and np.array_equal(a, b)
     fine_off, cexp, cidx, coarse_off, total = model(lab + 1, True, True)
     assert np.array_equal(a[fine_off], (lab + 1).astype(np.uint8)) and np.array_equal(a[coarse_off + cidx], cexp)
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_worker_pool_runs_every_part_exactly_once(threads):
+    """The persistent fork-join pool behind gsx_vote_view (own-share-then-help scheduling, per-thread claim counters):
+    thousands of back-to-back runs of varying size on one pool, every part executed exactly once in every run."""
+    lib = labeler._lib.lib()
+    assert lib.gsx_debug_workers_stress(threads, 3000, 150) == 0
+    assert lib.gsx_debug_workers_stress(threads, 500, 1) == 0
