@@ -3,7 +3,7 @@
 // Restates Web_Viewer_Gaussians_Selection/gaussians_selection.js ("gs.js"):
 //   splat_importance / splat_pack   processPlyBuffer   gs.js:513-582  (fp64 like JS numbers)
 //                                   generateTexture    gs.js:301-354  (4*Sigma as truncated fp16)
-//   depth_kernel / preprocess       runSort            gs.js:432-447  (depth int, 16-bit bucket)
+//   pre_kernel (depth + vertex + SH) runSort           gs.js:432-447  (depth int, 16-bit bucket)
 //                                   vertex shader      gs.js:696-750  (fp32, no contraction)
 //   bin / sort / ranges             the global stable counting sort (gs.js:450-457) becomes two stable
 //                                   radix sorts: splats by bucket, then (tile, splat) pairs by tile
