@@ -191,6 +191,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "host_pack") c->opt_host_pack = value != 0;
+    else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
         if ((int)value != c->opt_host_threads) {
@@ -322,6 +323,20 @@ int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_part
         return gsx::workers_stress(threads, runs, max_parts);
     } catch (...) {
         return -1;
+    }
+}
+int gsx_debug_widen_labels(int32_t threads, const uint8_t* bins, int64_t n, int32_t* labels_out) {
+    if (n < 0 || (n > 0 && (!bins || !labels_out))) return GSX_E_INVALID;
+    try {
+        if (threads > 1) {
+            gsx::Workers pool(threads);
+            gsx::host_widen_labels(&pool, labels_out, bins, (size_t)n);
+        } else {
+            gsx::host_widen_labels(nullptr, labels_out, bins, (size_t)n);
+        }
+        return GSX_OK;
+    } catch (...) {
+        return GSX_E_HIP;  /* the pool could not be created (thread / memory exhaustion) */
     }
 }
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,

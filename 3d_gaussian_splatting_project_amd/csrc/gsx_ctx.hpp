@@ -169,6 +169,7 @@ struct Ctx {
     // host hand-over (vote.hip): worker pool, pinned ring for the maps, pinned landing zone for the labels
     Workers* workers = nullptr;
     int opt_host_threads = 0;  // 0: default_host_threads()
+    int opt_labels_u8 = 1;     // 1: the labels cross PCIe as one byte each (bin = label + 1) and are widened by the workers; 0: as int32
     int opt_host_pack = 1;     // 1: host maps are narrowed to u8 by the workers (2.2 MB/map over PCIe); 0: raw copy + GPU pack kernel (8.3 MB/map)
     DevBuf dstage[kPinSlots];  // host_pack = 0: device-side landing zone of the raw map of each ring slot
     PinSlot ring[kPinSlots];   // host_pack = 0: raw maps
@@ -182,7 +183,7 @@ struct Ctx {
     int hring_next = 0;
     int pend_first = 0, pend_count = 0;  // packed maps of the filling group whose DMA has not been queued yet
     size_t pend_dst = 0;
-    void* h_labels = nullptr;  // pinned: n int32 labels + one int (the error flag) land here before the caller's array
+    void* h_labels = nullptr;  // pinned: n u8 bins (label + 1) + one int (the error flag) land here before the caller's array
     size_t h_labels_cap = 0;
     hipEvent_t h_ev[kLabelChunks] = {nullptr, nullptr, nullptr, nullptr};
     void* h_views = nullptr;   // pinned: view descriptors + culling planes on their way to d_views / d_cull
@@ -195,6 +196,7 @@ struct Ctx {
     bool planes_stale = false;  // planes hold a rewound run's votes; the next fresh flush overwrites them
     DevBuf cnt, fv;             // [bins][n_pad] counters / first-view codes (u8 or u16)
     DevBuf keys, labels;        // [n_pad] int32
+    DevBuf labels8;             // [n] u8: bin = label + 1, what labels_to_host sends over PCIe
     DevBuf bcnt, bcodes;        // > 255 views on one GPU: per-batch u8 count planes [S][bins][n_pad], tie codes u16 [S][n_pad]
     DevBuf cand, codes;         // exchange v3: candidate masks u32[8][sn] of this slab; tie codes u16[n_pad]
     bool labels_valid = false;

@@ -509,6 +509,46 @@ void host_copy(Workers* pool, void* dst, const void* src, size_t bytes) {
     pool->run((int)((bytes + j.chunk - 1) / j.chunk), copy_part, &j);
 }
 
+// ---- bins (u8) -> labels (int32) -------------------------------------------------------------------------------------
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void widen_avx2(int32_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n) {
+    const __m256i one = _mm256_set1_epi32(1);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const __m128i b = _mm_loadl_epi64(reinterpret_cast<const __m128i*>(src + i));
+        _mm256_storeu_si256(reinterpret_cast<__m256i*>(dst + i), _mm256_sub_epi32(_mm256_cvtepu8_epi32(b), one));
+    }
+    for (; i < n; ++i) dst[i] = (int32_t)src[i] - 1;
+}
+#endif
+static void widen_scalar(int32_t* __restrict__ dst, const uint8_t* __restrict__ src, size_t n) {
+    for (size_t i = 0; i < n; ++i) dst[i] = (int32_t)src[i] - 1;
+}
+struct WidenJob {
+    int32_t* dst;
+    const uint8_t* src;
+    size_t n, chunk;
+};
+static void widen_part(void* arg, int part) {
+    WidenJob* j = static_cast<WidenJob*>(arg);
+    const size_t lo = (size_t)part * j->chunk;
+    const size_t hi = lo + j->chunk < j->n ? lo + j->chunk : j->n;
+    if (lo >= hi) return;
+#if defined(__x86_64__)
+    if (g_avx2) return widen_avx2(j->dst + lo, j->src + lo, hi - lo);
+#endif
+    widen_scalar(j->dst + lo, j->src + lo, hi - lo);
+}
+void host_widen_labels(Workers* pool, int32_t* dst, const uint8_t* src, size_t n) {
+    WidenJob j{dst, src, n, (size_t)64 << 10};
+    const int parts = (int)((n + j.chunk - 1) / j.chunk);
+    if (!pool || parts <= 1) {
+        for (int p = 0; p < parts; ++p) widen_part(&j, p);
+        return;
+    }
+    pool->run(parts, widen_part, &j);
+}
+
 struct StressJob {
     std::atomic<int>* hits;
 };

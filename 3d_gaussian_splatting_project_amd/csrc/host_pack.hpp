@@ -50,6 +50,8 @@ int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HO
 int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst);
 // out = in, split over the pool (D2H epilogue: pinned -> the caller's pageable array)
 void host_copy(Workers* pool, void* dst, const void* src, size_t bytes);
+// dst[i] = (int)src[i] - 1 (bin -> label), split over the pool (D2H epilogue: the labels cross PCIe as one byte each)
+void host_widen_labels(Workers* pool, int32_t* dst, const uint8_t* src, size_t n);
 // test hook: `runs` fork-joins of varying size on ONE pool; returns the number of parts that did not run exactly once
 long long workers_stress(int threads, int runs, int max_parts);
 

@@ -1177,7 +1177,10 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
         ++c->pend_count;
         push_view(c, cam, L, off, img_w, img_h);
         c->hring_next = (s + 1) % kSlots;
-        if (c->pend_count == kDmaBatch || c->hring_next % kDmaBatch == 0) return vote_flush_pending(c);
+        // the last views of the run (as announced to vote_begin) go up one by one: a whole group waiting for its fourth map
+        // would put its 4-map DMA between the last hand-over and the vote
+        const bool tail = c->total_views - c->first_view - (int)c->views.size() < kDmaBatch;
+        if (tail || c->pend_count == kDmaBatch || c->hring_next % kDmaBatch == 0) return vote_flush_pending(c);
         return GSX_OK;
     }
     PinSlot& slot = c->ring[c->ring_next];
@@ -1277,7 +1280,8 @@ int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* 
 }
 
 // One DMA for the packed maps that wait in the filling group of the pinned ring (up to kDmaBatch consecutive slots =
-// consecutive pool offsets).  Called when the group is full, and by everything that needs the maps on the device.
+// consecutive pool offsets).  Called when the group is full, for each of the last maps of a run, and by everything that
+// needs the maps on the device.
 int vote_flush_pending(Ctx* c) {
     if (!c->pend_count) return GSX_OK;
     const int g = c->pend_first / kDmaBatch;
@@ -1288,8 +1292,8 @@ int vote_flush_pending(Ctx* c) {
     GSX_HIP(c, hipEventRecord(c->hring_ev[g], c->stream));
     c->hring_busy[g] = true;
     c->pend_count = 0;
-    // a group that was flushed before it was full is closed: the next map starts the next group
-    c->hring_next = ((g + 1) % kDmaGroups) * kDmaBatch;
+    // a group that was flushed before it was full keeps filling: its later slots are not in flight, and the event (recorded
+    // again by the next flush) always stands for the group's LAST copy, which is what the next lap waits for
     return GSX_OK;
 }
 
@@ -1610,12 +1614,36 @@ int vote_tiebreak_keys(Ctx* c) {
     return GSX_OK;
 }
 
-// Last step of every protocol: the labels (and the device-side range flag) to the host.  D2H lands in pinned memory
-// in kLabelChunks pieces; the worker threads copy piece i into the caller's (pageable) array while piece i+1 is
-// still on the link.  A map that gsx_vote_view_device packed with a label out of range fails the call here.
+// Last step of every protocol: the labels (and the device-side range flag) to the host.  A label is -1 .. 254, so it
+// crosses PCIe as ONE byte (bin = label + 1; labels_narrow_kernel, 3 MB instead of 12 MB for 3 M Gaussians: the D2H is
+// on the critical path of every run) into pinned memory, in kLabelChunks pieces; the worker threads widen piece i into
+// the caller's (pageable) int32 array while piece i+1 is still on the link.  A map that gsx_vote_view_device packed
+// with a label out of range fails the call here.
+static constexpr int kBadLabelWord = -2;  // errflag value: c->labels held something that is not a label (never a view index)
+__global__ __launch_bounds__(kBlock) void labels_narrow_kernel(const int* __restrict__ labels, long long n, uint8_t* __restrict__ out,
+                                                               int* __restrict__ errflag) {
+    const long long i4 = ((long long)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i4 >= n) return;
+    unsigned b[4];
+    if (i4 + 4 <= n) {
+        const int4 v = *reinterpret_cast<const int4*>(labels + i4);
+        b[0] = (unsigned)v.x + 1u, b[1] = (unsigned)v.y + 1u, b[2] = (unsigned)v.z + 1u, b[3] = (unsigned)v.w + 1u;
+        if ((b[0] | b[1] | b[2] | b[3]) > 255u) atomicMin(errflag, kBadLabelWord);
+        *reinterpret_cast<uint32_t*>(out + i4) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    } else {
+        for (long long i = i4; i < n; ++i) {
+            const unsigned bb = (unsigned)labels[i] + 1u;
+            if (bb > 255u) atomicMin(errflag, kBadLabelWord);
+            out[i] = (uint8_t)bb;
+        }
+    }
+}
+
 static int labels_to_host(Ctx* c, int32_t* labels_out) {
     c->labels_valid = true;
-    const size_t nbytes = labels_out && c->n > 0 ? sizeof(int) * (size_t)c->n : 0;
+    const size_t n = labels_out && c->n > 0 ? (size_t)c->n : 0;
+    const size_t esz = c->opt_labels_u8 ? 1 : sizeof(int);  // bytes per label on the link ("labels_u8" = 0: the A/B of DESIGN.md)
+    const size_t nbytes = n * esz;
     const size_t flag_off = (nbytes + 63) / 64 * 64;
     const size_t need = flag_off + 64;
     if (c->h_labels_cap < need) {
@@ -1627,28 +1655,40 @@ static int labels_to_host(Ctx* c, int32_t* labels_out) {
     }
     char* land = static_cast<char*>(c->h_labels);
     int* flag = reinterpret_cast<int*>(land + flag_off);
+    const char* src = c->labels.as<char>();
+    if (n && c->opt_labels_u8) {
+        GSX_HIP(c, c->labels8.ensure((n + 255) / 256 * 256));
+        ProfScope ps(c, "labels_narrow");
+        hipLaunchKernelGGL(labels_narrow_kernel, dim3(grid_for((long long)(n + 3) / 4)), dim3(kBlock), 0, c->stream, c->labels.as<int>(),
+                           (long long)n, c->labels8.as<uint8_t>(), c->errflag.as<int>());
+        GSX_HIP(c, hipGetLastError());
+        src = c->labels8.as<char>();
+    }
     GSX_HIP(c, hipMemcpyAsync(flag, c->errflag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    if (nbytes) {
+    if (n) {
         const int chunks = nbytes >= ((size_t)1 << 20) ? kLabelChunks : 1;
-        const size_t per = ((nbytes + chunks - 1) / chunks + 4095) / 4096 * 4096;
+        const size_t per = ((n + chunks - 1) / chunks + 4095) / 4096 * 4096;  // labels per chunk
         for (int k = 0; k < chunks; ++k) {
-            const size_t lo = std::min(nbytes, per * k), hi = std::min(nbytes, per * (k + 1));
-            if (lo < hi)
-                GSX_HIP(c, hipMemcpyAsync(land + lo, c->labels.as<char>() + lo, hi - lo, hipMemcpyDeviceToHost, c->stream));
+            const size_t lo = std::min(n, per * k), hi = std::min(n, per * (k + 1));
+            if (lo < hi) GSX_HIP(c, hipMemcpyAsync(land + lo * esz, src + lo * esz, (hi - lo) * esz, hipMemcpyDeviceToHost, c->stream));
             if (!c->h_ev[k]) GSX_HIP(c, hipEventCreateWithFlags(&c->h_ev[k], hipEventDisableTiming));
             GSX_HIP(c, hipEventRecord(c->h_ev[k], c->stream));
         }
         Workers* w = host_workers(c);
         for (int k = 0; k < chunks; ++k) {
-            const size_t lo = std::min(nbytes, per * k), hi = std::min(nbytes, per * (k + 1));
+            const size_t lo = std::min(n, per * k), hi = std::min(n, per * (k + 1));
             GSX_HIP(c, hipEventSynchronize(c->h_ev[k]));
-            if (lo < hi) host_copy(w, reinterpret_cast<char*>(labels_out) + lo, land + lo, hi - lo);
+            if (lo >= hi) continue;
+            if (c->opt_labels_u8) host_widen_labels(w, labels_out + lo, reinterpret_cast<const uint8_t*>(land) + lo, hi - lo);
+            else host_copy(w, labels_out + lo, land + lo * esz, (hi - lo) * esz);
         }
     }
     GSX_HIP(c, hipStreamSynchronize(c->stream));
     if (*flag != kNoBadView) {
         const int view = *flag;
         GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0x7f, sizeof(int), c->stream));
+        if (view == kBadLabelWord)
+            return fail(c, GSX_E_STATE, "the label buffer holds a value outside [-1, 254] (a corrupt exchange buffer?)");
         return fail(c, GSX_E_RANGE, "the segmentation map of view %d (gsx_vote_view_device) holds a label outside [-1, %d]", view,
                     c->n_classes - 1);
     }

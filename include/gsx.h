@@ -93,6 +93,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               pixel boundary (and any non-finite case) take the exact IEEE divisions.  Bit-identical
  *                               (tested on 7e7 pairs and at pixel boundaries) but measured 1 % SLOWER: 15 fewer fp64
  *                               instructions per visible pair, yet both axes are evaluated before the first early-out
+ *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
+ *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
  *   "blend_pk2"    (default 1)  rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four (one wave per tile)
  *   "render_phases" (default 2) rasterizer: a frame is binned, sorted and blended front to back in this many DEPTH
@@ -182,7 +184,9 @@ int32_t gsx_vote_num_views(const gsx_ctx* ctx);
 /* forget accumulated votes but keep the staged views: the next flush/finalize votes them again */
 int gsx_vote_rewind(gsx_ctx* ctx);
 /* single-GPU end: runs the fused kernel (+ arg-max) and leaves int32 labels on the device.
- * labels_out: host array of n int32, or NULL to skip the device-to-host copy. */
+ * labels_out: host array of n int32, or NULL to skip the device-to-host copy.  A label is -1 .. 254, so the copy moves
+ * ONE byte per Gaussian (label + 1) into pinned memory and the worker threads widen it into labels_out (option
+ * "labels_u8" = 0: int32 over the link, the A/B of DESIGN.md section 3). */
 int gsx_vote_finalize(gsx_ctx* ctx, int32_t* labels_out);
 /* device pointer of the n int32 labels written by gsx_vote_finalize / gsx_vote_labels_from_keys */
 void* gsx_vote_labels_device(gsx_ctx* ctx);
@@ -361,6 +365,9 @@ int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h
 /* test hook, host only: `runs` fork-joins of pseudo-random size (1..max_parts parts) on ONE worker pool of `threads` threads;
  * returns how many parts did not run exactly once (0 = the pool is sound), -1 if the pool could not be created */
 int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_parts);
+/* test hook, host only: the D2H epilogue's widening pass - labels_out[i] = bins[i] - 1 (the labels cross PCIe as one byte
+ * each, bin = label + 1), on `threads` worker threads */
+int gsx_debug_widen_labels(int32_t threads, const uint8_t* bins, int64_t n, int32_t* labels_out);
 /* statistics: (wave of 64 Gaussians, view) pairs the vote kernels skipped through the wave culling since the context
  * was created or since the last call with reset != 0 */
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);

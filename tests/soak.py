@@ -32,6 +32,7 @@ with gsx.Context(0) as c:
                 "flat_project": int(rng.random() < 0.85), "wave_cull": int(rng.random() < 0.8), "seg_coarse": int(rng.random() < 0.8),
                 "xcd_swizzle": int(rng.choice([0, 1, 4, 32])), "fast_div": int(rng.random() < 0.3), "lds_batch": int(rng.random() < 0.2)}
         opts["host_threads"] = int(rng.choice([1, 3, 16]))
+        opts["labels_u8"] = int(rng.random() < 0.8)
         for k, v in opts.items():
             c.set_option(k, v)
         spread = float(rng.choice([0.3, 2.0, 8.0, 40.0]))

@@ -104,3 +104,18 @@ def test_worker_pool_runs_every_part_exactly_once(threads):
     lib = labeler._lib.lib()
     assert lib.gsx_debug_workers_stress(threads, 3000, 150) == 0
     assert lib.gsx_debug_workers_stress(threads, 500, 1) == 0
+
+
+def test_labels_cross_pcie_as_bytes_widened_on_the_host():
+    """The D2H epilogue (vote.hip labels_to_host): bins u8 -> labels int32, every value, ragged sizes, 1 and 5 threads."""
+    lib = labeler._lib.lib()
+    rng = np.random.default_rng(7)
+    for n in (0, 1, 7, 8, 255, 65536, 65537, 200_003):
+        bins = rng.integers(0, 256, size=n, dtype=np.uint8)
+        if n >= 256:
+            bins[:256] = np.arange(256, dtype=np.uint8)
+        for threads in (1, 5):
+            out = np.full(n + 1, 77, np.int32)
+            assert lib.gsx_debug_widen_labels(threads, bins.ctypes.data, n, out.ctypes.data) == 0
+            assert np.array_equal(out[:n], bins.astype(np.int32) - 1) and out[n] == 77
+    assert lib.gsx_debug_widen_labels(1, None, 4, None) == labeler._lib.GSX_E_INVALID

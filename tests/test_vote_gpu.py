@@ -86,7 +86,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
                  {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
                  {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
@@ -622,6 +622,43 @@ def test_device_map_range_error_is_reported_with_the_labels(ctx, gsx):
     ctx.vote_begin(10, 0, 2)                    # a new run starts clean
     ctx.vote_view(cam, good)
     assert set(ctx.vote_finalize().tolist()) <= {3, -1}
+
+
+def test_labels_leave_the_device_as_bytes(gsx):
+    """labels_to_host: one byte per Gaussian over PCIe (bin = label + 1), widened by the host workers.  255 classes use the
+    whole byte (label 254 = bin 255, -1 = bin 0); sizes around the chunking and vector widths; both link formats agree; a label
+    buffer that holds something else (gsx_vote_labels_from_sorted takes it from the caller) is refused, not truncated."""
+    import torch
+    rng = np.random.default_rng(99)
+    for n in (1, 5, 1023, 70_000, 1_100_003):
+        V, W, H = 3, 96, 64
+        pos, cams, _ = scene.make_scene(n, V, W, H, config_id=31, convention="w2c")
+        segs = [rng.integers(-1, 255, size=(H, W), dtype=np.int32) for _ in range(V)]
+        for s in segs:
+            s[:2, :] = 254
+            s[2:4, :] = -1
+        sizes = [(W, H)] * V
+        want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+        got = {}
+        for u8 in (1, 0):
+            with gsx.Context(0) as c:
+                c.set_option("labels_u8", u8)
+                got[u8] = run_gpu(c, pos, cams, segs, sizes, n_classes=255).vote_finalize()
+                assert got[u8].dtype == np.int32 and np.array_equal(got[u8], want), (n, u8)
+        if n >= 70_000:
+            assert want.max() == 254 and want.min() == -1
+    with gsx.Context(0) as c:
+        n = 5000
+        pos, cams, segs = scene.make_scene(n, 2, 64, 48, config_id=32, convention="w2c")
+        run_gpu(c, pos, cams, segs, [(64, 48)] * 2)
+        bad = torch.zeros(n + 256, dtype=torch.int32, device="cuda:0")
+        bad[n // 2] = 255                                   # not a label: labels are -1 .. 254
+        torch.cuda.synchronize()
+        with pytest.raises(gsx.GsxError, match="outside"):
+            c.vote_labels_from_sorted(bad.data_ptr())
+        good = torch.full((n + 256,), 254, dtype=torch.int32, device="cuda:0")
+        torch.cuda.synchronize()
+        assert (c.vote_labels_from_sorted(good.data_ptr()) == 254).all()   # the flag was reset; the context works on
 
 
 def test_empty_and_degenerate(ctx):
