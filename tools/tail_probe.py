@@ -34,7 +34,7 @@ for r in range(RUNS + 3):
 a = np.array(rows)
 med = np.median(a, axis=0)
 print(f"hand-over {med[0]:.3f} ms  tail {med[1]:.3f} ms  span {med[2]:.3f} ms   (median of {RUNS}; min span {a[:,2].min():.3f}, tail min {a[:,1].min():.3f})")
-for name, val in (("labels_u8", 0), ("labels_u8", 1)):
+for name, val in (("labels_u8", 0), ("labels_u8", 1), ("seg_coarse", 0), ("seg_coarse", 1), ("seg_coarse", 0), ("seg_coarse", 1)):
     ctx.set_option(name, val)
     rows = []
     for r in range(RUNS + 3):
