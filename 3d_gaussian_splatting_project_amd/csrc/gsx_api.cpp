@@ -186,7 +186,6 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     } else if (k == "exchange_local") c->opt_local_codes = value != 0;
     else if (k == "fast_div") c->opt_fast_div = value != 0;
     else if (k == "lds_batch") c->opt_lds_batch = value != 0;
-    else if (k == "vote_pipeline") c->opt_vote_pipeline = value != 0;
     else if (k == "flat_project") c->opt_flat_project = value != 0;
     else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;

@@ -136,7 +136,6 @@ struct Ctx {
     int opt_vote_unroll = 8;   // views whose seg gathers are in flight together: 1, 2, 4 or 8
     int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
     int opt_local_codes = 0;   // see Ctx::local_codes
-    int opt_vote_pipeline = 0; // software-pipelined fused kernel (coarse gathers two chunks ahead, exact pixels one chunk ahead)
     int opt_lds_batch = 0;     // read a chunk's LDS counters in one round trip (repeats resolved in registers)
     int opt_blend_pk2 = 1;     // rasterizer: two pixels per thread, packed fp32 maths
     int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %; the test costs more than the sort saves)

@@ -611,196 +611,6 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 }
 
 // -------------------------------------------------------------------------------------------------
-// The same walk, software-pipelined over THREE chunks of U views (two-level maps, kDivFlatCoarse batches only).
-// In vote_fused_labels_kernel a wave projects a chunk, waits for its coarse bytes, waits again for the exact
-// pixels of the boundary lanes, then runs the dependent LDS chain: with four waves per SIMD (the histograms fill
-// the LDS) there are moments when all four are parked and the vector ALU - the unit that binds the kernel - idles
-// (VALU busy 0.67).  Here every iteration
-//     issues   the coarse gathers of chunk c+2  (the fp64 projections: ~50 vector instructions per view),
-//     resolves chunk c+1                        (its coarse bytes were requested one iteration ago; requests the
-//                                                exact pixel for lanes on a mixed cell),
-//     applies  chunk c                          (its exact pixels were requested one iteration ago; LDS votes),
-// so every gather has a whole iteration of arithmetic to arrive.  The memory counter (vmcnt) retires in order, and
-// the compiler can only wait for "all but the N youngest" if N is the same on every path, so in the steady state
-// every view issues EXACTLY one coarse and one fine load (lanes that need nothing read byte 0 of the map: a line
-// every wave of the CU keeps hot) and there is no branch around a load.  Views the wave culling rejects are not
-// skipped inside the loop - they never enter it: the wave walks a table of its LIVE views (live_views below), so a chunk
-// is U live views and only the last chunk can be ragged (handled outside the steady state, where conservative waits do
-// not matter).  Same votes, in the same (reverse view) order, same labels.
-// -------------------------------------------------------------------------------------------------
-template <int U>
-struct PipeStage {
-    uint8_t bin[U];    // coarse byte (a dummy where `vis` is clear).  Bytes on purpose: as 32-bit loop variables the
-    uint8_t fine[U];   // optimiser narrows them itself and widens them in the loop's LATCH - a use of every load in flight
-    unsigned pix[U];   // xi | yi << 16
-    unsigned vis;      // bit u: this lane's Gaussian is visible in the chunk's u-th view
-};
-
-// position of the r-th (0-based) set bit of a 64-bit word; any value if the word has fewer (never used then)
-__device__ __forceinline__ unsigned nth_set_bit64(unsigned lo, unsigned hi, unsigned r) {
-    const unsigned clo = (unsigned)__popc(lo);
-    const bool up = r >= clo;
-    unsigned x = up ? hi : lo, base = up ? 32u : 0u;
-    r = up ? r - clo : r;
-#pragma unroll
-    for (unsigned wd = 16; wd >= 1; wd >>= 1) {
-        const unsigned cnt = (unsigned)__popc(x & ((1u << wd) - 1u));
-        const bool u2 = r >= cnt;
-        r = u2 ? r - cnt : r;
-        x = u2 ? x >> wd : x;
-        base += u2 ? wd : 0u;
-    }
-    return base;
-}
-
-// The wave's LIVE views (not culled), in reverse view order, as a per-lane table: lane l of list[k] holds the index of
-// live view number 64k + l.  Built once per wave (a per-lane "select the q-th set bit" over the cull mask, ~45 vector
-// instructions per 64 views); the walk then costs one v_readlane per view instead of scalar mask bookkeeping - the scalar
-// unit is shared by the four SIMDs of a CU and is as busy as the vector ALUs in this kernel.
-struct LiveList {
-    unsigned list[4];
-    int n;  // live views (wave-uniform)
-};
-
-__device__ __forceinline__ LiveList live_views(const CullMasks& k, int nviews) {
-    LiveList L;
-    unsigned long long w[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int span = nviews - 64 * j;  // reverse indices 64j .. 64j+63 that exist
-        const unsigned long long exist = span >= 64 ? ~0ull : span > 0 ? (1ull << span) - 1ull : 0ull;
-        w[j] = ~k.m[j] & exist;
-    }
-    const unsigned c0 = (unsigned)__popcll(w[0]), c1 = c0 + (unsigned)__popcll(w[1]), c2 = c1 + (unsigned)__popcll(w[2]);
-    L.n = (int)(c2 + (unsigned)__popcll(w[3]));
-    const unsigned lane = threadIdx.x & 63u;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        L.list[b] = 0;
-        if (64 * b < L.n) {  // wave-uniform
-            const unsigned q = 64u * b + lane;
-            const unsigned j = (q >= c0) + (q >= c1) + (q >= c2);
-            const unsigned r = q - (j == 0 ? 0u : j == 1 ? c0 : j == 2 ? c1 : c2);
-            const unsigned long long W = j == 0 ? w[0] : j == 1 ? w[1] : j == 2 ? w[2] : w[3];
-            const unsigned pos = 64u * j + nth_set_bit64((unsigned)W, (unsigned)(W >> 32), r);
-            L.list[b] = (unsigned)(nviews - 1) - pos;  // lanes past the last live view hold garbage nobody reads
-        }
-    }
-    return L;
-}
-
-// the table block that holds live views 64b .. 64b+63 (b wave-uniform, changes every 64 / U chunks)
-__device__ __forceinline__ unsigned live_block(const LiveList& L, int b) {
-    return b == 0 ? L.list[0] : b == 1 ? L.list[1] : b == 2 ? L.list[2] : L.list[3];
-}
-
-// FULL: the chunk has U views.  Otherwise `count` (wave-uniform) of them; the other slots issue nothing and vote nothing.
-// q0 = number of the chunk's first live view (a multiple of U, so the chunk sits in ONE table block).
-template <int U, bool FULL>
-__device__ __forceinline__ void pipe_issue(const ViewDesc* __restrict__ views, const LiveList& L, int q0, int count, double X,
-                                           double Y, double Z, PipeStage<U>& s) {
-    s.vis = 0;
-    const unsigned blk = live_block(L, q0 >> 6);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        s.pix[u] = 0;
-        s.bin[u] = 0;
-        if (FULL || u < count) {  // wave-uniform
-            const int v = __builtin_amdgcn_readlane((int)blk, (q0 & 63) + u);
-            const ViewRegs vd = load_view(views + v);
-            unsigned off = 0;  // invisible lane: byte 0 of the coarse map
-            int xi, yi;
-            if (project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
-                s.pix[u] = (unsigned)xi | ((unsigned)yi << 16);
-                const unsigned cx = (unsigned)xi >> 2, cy = (unsigned)yi >> 2;
-                off = __umul24(cx >> 4, (unsigned)vd.coarse_row_bytes) + (cx & 15u) + (cy << 4);
-                s.vis |= 1u << u;
-            }
-            asm volatile("" : "+v"(off));  // keep ONE load behind the merge (base in SGPRs), not one address per path
-            s.bin[u] = ((global_u8_ptr)((unsigned long long)vd.seg_off + vd.coarse_delta))[off];
-        }
-    }
-}
-
-template <int U, bool FULL>
-__device__ __forceinline__ void pipe_resolve(const ViewDesc* __restrict__ views, const LiveList& L, int q0, int count,
-                                             PipeStage<U>& s) {
-    const unsigned blk = live_block(L, q0 >> 6);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        s.fine[u] = 0;
-        if (FULL || u < count) {  // wave-uniform
-            const ViewDesc* __restrict__ vp = views + __builtin_amdgcn_readlane((int)blk, (q0 & 63) + u);
-            // lanes on a uniform cell (and invisible ones) read byte 0 of the map
-            const bool mixed = ((s.vis >> u) & 1u) && s.bin[u] == 255;
-            const unsigned xi = s.pix[u] & 0xffffu, yi = s.pix[u] >> 16;
-            unsigned off = mixed ? __umul24(xi >> 4, (unsigned)vp->seg_row_bytes) + (xi & 15u) + (yi << 4) : 0u;
-            asm volatile("" : "+v"(off));
-            s.fine[u] = ((global_u8_ptr)(unsigned long long)vp->seg_off)[off];
-        }
-    }
-}
-
-template <int U>
-__global__ __launch_bounds__(kBlock) void vote_fused_labels_pipe_kernel(FusedParams p, const ViewDesc* __restrict__ views,
-                                                                        int* __restrict__ labels) {
-    static_assert(64 % U == 0, "a chunk must not straddle two blocks of the live-view table");
-    extern __shared__ uint32_t lds[];
-    uint32_t* row = lds + threadIdx.x * p.stride_dw;
-    uint8_t* h = reinterpret_cast<uint8_t*>(row);
-    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
-    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
-    const bool valid = i < p.n;
-    const double X = valid ? (double)p.x[i] : __builtin_nan("");  // NaN: never visible (see vote_fused_labels_kernel)
-    const double Y = valid ? (double)p.y[i] : 0.0;
-    const double Z = valid ? (double)p.z[i] : 0.0;
-    int best = -1, bestc = 0;
-    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
-    const LiveList L = live_views(cmask, p.nviews);
-    const int nchunks = (L.n + U - 1) / U, nfull = L.n / U;
-    auto count_of = [&](int c) { return L.n - c * U < U ? L.n - c * U : U; };
-    auto apply = [&](const PipeStage<U>& s) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if ((s.vis >> u) & 1u) {
-                const int b = s.bin[u] == 255 ? (int)s.fine[u] : (int)s.bin[u];  // mixed cell: the exact pixel decides
-                const int c = h[b] + 1;                                           // dls.py:295
-                h[b] = (uint8_t)c;
-                if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
-                    bestc = c;
-                    best = b;
-                }
-            }
-        }
-    };
-    if (nchunks > 0) {
-        PipeStage<U> s0, s1, s2;
-        pipe_issue<U, false>(views, L, 0, count_of(0), X, Y, Z, s0);
-        if (nchunks > 1) pipe_issue<U, false>(views, L, U, count_of(1), X, Y, Z, s1);
-        pipe_resolve<U, false>(views, L, 0, count_of(0), s0);
-        int c = 0;  // invariant: chunk c sits resolved in s0, chunk c+1 (if any) issued in s1
-        while (c + 4 < nfull) {  // steady state: chunks c .. c+4 are all full, no branch around a load
-            pipe_issue<U, true>(views, L, (c + 2) * U, U, X, Y, Z, s2), pipe_resolve<U, true>(views, L, (c + 1) * U, U, s1), apply(s0);
-            pipe_issue<U, true>(views, L, (c + 3) * U, U, X, Y, Z, s0), pipe_resolve<U, true>(views, L, (c + 2) * U, U, s2), apply(s1);
-            pipe_issue<U, true>(views, L, (c + 4) * U, U, X, Y, Z, s1), pipe_resolve<U, true>(views, L, (c + 3) * U, U, s0), apply(s2);
-            c += 3;
-        }
-        for (;;) {  // the last <= 5 chunks: the same schedule with tests (and whatever waits the compiler finds safe)
-            if (c + 2 < nchunks) pipe_issue<U, false>(views, L, (c + 2) * U, count_of(c + 2), X, Y, Z, s2);
-            if (c + 1 < nchunks) pipe_resolve<U, false>(views, L, (c + 1) * U, count_of(c + 1), s1);
-            apply(s0);
-            if (++c >= nchunks) break;
-            s0 = s1;
-            s1 = s2;
-        }
-    }
-    if (valid) {
-        const long long o = p.perm ? (long long)p.perm[i] : i;
-        labels[o] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // exchange protocol v3, rank-local part 1: the same walk as the labels kernel (u8 counters, 16 waves/CU)
 // but the only output is this rank's COUNT plane, u8 [slab][bins][sn].  No first-view plane: ties are
 // resolved later, for the tied Gaussians only, by vote_tie_kernel.
@@ -1935,8 +1745,6 @@ static int labels_one_batch(Ctx* c, const VoteRange& r, const uint32_t* perm, in
     static const K table[3][5][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
 #undef GSX_ROW
     K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
-    if (c->opt_vote_pipeline && div_mode(c) == kDivFlatCoarse)
-        k = c->opt_vote_unroll == 8 ? vote_fused_labels_pipe_kernel<8> : c->opt_vote_unroll == 4 ? vote_fused_labels_pipe_kernel<4> : k;
     int rc = set_lds(c, k, lds);
     if (rc) return rc;
     ProfScope ps(c, "vote_fused_labels");

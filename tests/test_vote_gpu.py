@@ -86,7 +86,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
                  {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"vote_pipeline": 0}, {"vote_pipeline": 1, "vote_unroll": 4}, {"vote_pipeline": 1, "wave_cull": 0}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
                  {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
