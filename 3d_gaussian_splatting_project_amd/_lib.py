@@ -64,6 +64,8 @@ _SIGS = {
     "gsx_vote_views_device": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32]),
     "gsx_debug_workers_stress": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "gsx_debug_host_pack_compact": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                              C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "gsx_debug_widen_labels": (C.c_int, [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "gsx_debug_host_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -88,6 +90,7 @@ _SIGS = {
     "gsx_vote_labels_from_sorted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_vote_export": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "gsx_vote_pool_bytes": (C.c_int64, [C.c_void_p]),
+    "gsx_vote_link_bytes": (C.c_int64, [C.c_void_p]),
     "gsx_vote_import": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "gsx_vote_slab_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "gsx_host_threads": (C.c_int, [C.c_void_p]),

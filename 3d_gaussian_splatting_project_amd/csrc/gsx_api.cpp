@@ -192,6 +192,8 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
+    else if (k == "host_compact") c->opt_host_compact = value != 0;
+    else if (k == "ablate") c->opt_ablate = (int)value;
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
         if ((int)value != c->opt_host_threads) {
@@ -339,6 +341,14 @@ int gsx_debug_widen_labels(int32_t threads, const uint8_t* bins, int64_t n, int3
         return GSX_E_HIP;  /* the pool could not be created (thread / memory exhaustion) */
     }
 }
+int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t threads, uint8_t* out,
+                                int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad) {
+    try {
+        return gsx::debug_host_pack_compact(seg, seg_dtype, w, h, n_classes, threads, out, out_cap, bytes, table_bytes, stream_off, bad);
+    } catch (...) {
+        return GSX_E_HIP;
+    }
+}
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad) {
@@ -437,6 +447,10 @@ int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void**
 int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
     return (c && c->vote_begun && !c->pool_base) ? (int64_t)((c->seg_used + 255) / 256 * 256) : 0;
+}
+int64_t gsx_vote_link_bytes(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return (c && c->vote_begun) ? (int64_t)c->compact_bytes : 0;
 }
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes) {

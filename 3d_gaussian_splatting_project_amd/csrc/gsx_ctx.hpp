@@ -108,6 +108,7 @@ struct PinSlot {
 };
 static constexpr int kPinSlots = 4;
 static constexpr int kDmaBatch = 4;    // packed host maps per H2D copy (one hipMemcpyAsync + event record costs ~6 us of host time)
+static constexpr int kCompactBatch = 16;  // compact records per H2D copy and expansion launch (as many as fit into a group's part of the ring)
 static constexpr int kDmaGroups = 3;   // ring = kDmaGroups groups of kDmaBatch slots: one filling, one or two in flight
 static constexpr int kLabelChunks = 4;
 static constexpr int kNoBadView = 0x7f7f7f7f;  // errflag value meaning "every device-side map was in range"
@@ -169,6 +170,8 @@ struct Ctx {
     // host hand-over (vote.hip): worker pool, pinned ring for the maps, pinned landing zone for the labels
     Workers* workers = nullptr;
     int opt_host_threads = 0;  // 0: default_host_threads()
+    int opt_host_compact = 1;  // host maps cross PCIe in the compact form (coarse level + the mixed cells' blocks), expanded on the GPU
+    int opt_ablate = 0;        // timing experiments only (results invalid): 1 = host maps are packed but not copied, 2 = copied but not packed
     int opt_labels_u8 = 1;     // 1: the labels cross PCIe as one byte each (bin = label + 1) and are widened by the workers; 0: as int32
     int opt_host_pack = 1;     // 1: host maps are narrowed to u8 by the workers (2.2 MB/map over PCIe); 0: raw copy + GPU pack kernel (8.3 MB/map)
     DevBuf dstage[kPinSlots];  // host_pack = 0: device-side landing zone of the raw map of each ring slot
@@ -183,6 +186,19 @@ struct Ctx {
     int hring_next = 0;
     int pend_first = 0, pend_count = 0;  // packed maps of the filling group whose DMA has not been queued yet
     size_t pend_dst = 0;
+    // compact transfer form: the records of a group lie back to back in its part of the ring
+    bool hring_compact = false;
+    size_t grp_used = 0;                 // bytes of the filling group in use
+    size_t pend_lo = 0;                  // where the pending records start in the group
+    size_t pend_rec[kCompactBatch] = {}; // their offsets in the group
+    size_t pend_map[kCompactBatch] = {}; // their maps' offsets in the pool
+    int cgrp = 0, grp_recs = 0;          // the filling group and the records it holds
+    int pend_group = 0;                  // group of the pending records
+    MapLayout pend_L;                    // their geometry (one expansion launch = one geometry)
+    DevBuf cstage;                       // device staging of one group of records
+    void* h_scratch = nullptr;           // host: the narrowed strips of the map being packed (ordinary memory)
+    size_t h_scratch_cap = 0;
+    long long compact_bytes = 0;         // statistics: bytes of host maps sent over PCIe since vote_begin (compact records or pool form)
     void* h_labels = nullptr;  // pinned: n u8 bins (label + 1) + one int (the error flag) land here before the caller's array
     size_t h_labels_cap = 0;
     hipEvent_t h_ev[kLabelChunks] = {nullptr, nullptr, nullptr, nullptr};
@@ -255,6 +271,8 @@ int vote_flush_pending(Ctx* c);  // queue the DMA of packed host maps that are s
 void vote_release_host(Ctx* c);  // pinned buffers, events, worker pool (gsx_destroy)
 int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes, int tiled, int coarse, int threads,
                     uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off, int32_t* bad);
+int debug_host_pack_compact(const void* seg, int seg_dtype, int w, int h, int n_classes, int threads, uint8_t* out, int64_t out_cap,
+                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad);
 int vote_rewind(Ctx* c);
 int vote_finalize(Ctx* c, int32_t* labels_out);
 int vote_flush(Ctx* c);

@@ -383,8 +383,16 @@ struct PackJob {
     const void* seg;
     MapLayout L;
     unsigned bins;
-    uint8_t* dst;
-    std::atomic<unsigned> bad{0};
+    uint8_t* dst;     // full-resolution level (strips)
+    uint8_t* coarse;  // coarse level (plain form: dst + L.coarse_off)
+    // compact form only
+    uint32_t* table = nullptr;
+    uint8_t* stream = nullptr;
+    // written by the workers: on lines of their own (every band reads the fields above; a counter next to them would pull
+    // that line out of sixteen caches 135 times per map)
+    alignas(64) std::atomic<unsigned> bad{0};
+    alignas(64) std::atomic<uint32_t> blocks{0};
+    char pad_[60] = {};
 };
 
 // one band of 8 pixel rows = one 128-B line of every strip (and two rows of coarse cells).  The source is read ROW BY
@@ -438,13 +446,59 @@ static void pack_band_tiled(PackJob* j, int band) {
                 }
                 const int cx0 = s * 4;  // first cell of the strip
                 const int ncell = L.cw - cx0 >= 4 ? 4 : L.cw - cx0;
-                uint8_t* co = dst + L.coarse_off + (size_t)(cx0 >> 4) * L.cstrip_bytes + (cx0 & 15) + (size_t)cy * 16;
+                uint8_t* co = j->coarse + (size_t)(cx0 >> 4) * L.cstrip_bytes + (cx0 & 15) + (size_t)cy * 16;
                 if (ncell == 4) std::memcpy(co, &word, 4);
                 else std::memcpy(co, &word, (size_t)ncell);
             }
         }
     }
     if (bad) j->bad.fetch_or(1u, std::memory_order_relaxed);
+    if (j->stream) {
+        // compact form: the band's mixed cells (coarse byte 255) go to the stream as 16-byte blocks, cell row by cell row
+        // and inside a row by cell column; uniform cells are their coarse byte.  The strips' lines of this band were
+        // written a moment ago: they are in this core's cache.  Cost ~ the number of mixed cells: a row of 16 cells is one
+        // compare + movemask.
+        constexpr int kMaxCs = 1024;  // coarse strips of a 65535-pixel row
+        uint16_t masks[2][kMaxCs];
+        const int ncs = (L.cw + 15) >> 4;
+        uint32_t n = 0;
+        int rows_here = 0;
+        for (int cyl = 0; cyl < 2; ++cyl) {
+            const int cy = band * 2 + cyl;
+            if (cy >= L.ch) break;
+            rows_here = cyl + 1;
+            if (L.cw & 15)  // the cells past the map's last cell column: defined bytes (the level goes into the pool as it is)
+                std::memset(j->coarse + (size_t)(L.cw >> 4) * L.cstrip_bytes + (size_t)cy * 16 + (L.cw & 15), 0, (size_t)(16 - (L.cw & 15)));
+            for (int cs = 0; cs < ncs; ++cs) {
+                const uint8_t* co = j->coarse + (size_t)cs * L.cstrip_bytes + (size_t)cy * 16;
+                unsigned m;
+#if defined(__x86_64__)
+                m = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(co)), _mm_set1_epi8((char)255)));
+#else
+                m = 0;
+                for (int k = 0; k < 16; ++k) m |= (unsigned)(co[k] == 255) << k;
+#endif
+                masks[cyl][cs] = (uint16_t)m;  // padding cells are 0, never 255
+                n += (unsigned)__builtin_popcount(m);
+            }
+        }
+        const uint32_t first = n ? j->blocks.fetch_add(n, std::memory_order_relaxed) : 0u;
+        j->table[band] = first;
+        uint8_t* out = j->stream + (size_t)first * 16;
+        for (int cyl = 0; cyl < rows_here && n; ++cyl) {
+            const uint8_t* rows = dst + (size_t)(y0 + cyl * 4) * 16;  // row 4*cyl of the band in strip 0
+            for (int cs = 0; cs < ncs; ++cs) {
+                for (unsigned m = masks[cyl][cs]; m; m &= m - 1) {
+                    const int cx = cs * 16 + __builtin_ctz(m);
+                    const uint8_t* q = rows + (size_t)(cx >> 2) * L.strip_bytes + (cx & 3) * 4;  // rows 16 bytes apart
+                    uint32_t r[4];
+                    std::memcpy(&r[0], q, 4), std::memcpy(&r[1], q + 16, 4), std::memcpy(&r[2], q + 32, 4), std::memcpy(&r[3], q + 48, 4);
+                    std::memcpy(out, r, 16);
+                    out += 16;
+                }
+            }
+        }
+    }
 }
 
 template <typename T, unsigned ADD>
@@ -473,6 +527,7 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
     j.L = L;
     j.bins = (unsigned)bins;
     j.dst = dst;
+    j.coarse = dst + L.coarse_off;
     void (*fn)(void*, int) = seg_dtype == 0   ? pack_part<int32_t, 1u>
                              : seg_dtype == 1 ? pack_part<int64_t, 1u>
                              : seg_dtype == 2 ? pack_part<uint8_t, 0u>
@@ -486,6 +541,44 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
     else
         for (int b = 0; b < bands; ++b) fn(&j, b);
     if (!L.strip_bytes) std::memset(dst + (size_t)L.w * L.h, 0, 4);  // the row-major form's 4 bytes of slack
+    return j.bad.load() ? 1 : 0;
+}
+
+CompactLayout compact_layout(const MapLayout& L) {
+    CompactLayout C;
+    C.bands = (L.h + 7) / 8;
+    C.table_bytes = ((size_t)C.bands * 4 + 255) / 256 * 256;
+    C.coarse_bytes = (L.map_bytes - L.coarse_off + 255) / 256 * 256;
+    C.stream_off = C.table_bytes + C.coarse_bytes;
+    C.capacity = C.stream_off + (size_t)L.cw * (size_t)L.ch * 16;
+    return C;
+}
+
+int host_pack_map_compact(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* scratch, uint8_t* rec,
+                          size_t* blocks) {
+    const CompactLayout C = compact_layout(L);
+    PackJob j;
+    j.seg = seg;
+    j.L = L;
+    j.bins = (unsigned)bins;
+    j.dst = scratch;
+    j.coarse = rec + C.table_bytes;
+    j.table = reinterpret_cast<uint32_t*>(rec);
+    j.stream = rec + C.stream_off;
+    void (*fn)(void*, int) = seg_dtype == 0   ? pack_part<int32_t, 1u>
+                             : seg_dtype == 1 ? pack_part<int64_t, 1u>
+                             : seg_dtype == 2 ? pack_part<uint8_t, 0u>
+                                              : pack_part<uint8_t, 1u>;
+    std::memset(rec + (size_t)C.bands * 4, 0, C.table_bytes - (size_t)C.bands * 4);
+    // cell rows past the map (a coarse strip has room for a multiple of 8): defined bytes, like the cell columns past the
+    // map that the bands clear - the level goes into the pool as it is
+    const size_t row_room = (size_t)L.cstrip_bytes / 16;
+    for (int cs = 0; cs * 16 < L.cw && row_room > (size_t)L.ch; ++cs)
+        std::memset(j.coarse + (size_t)cs * L.cstrip_bytes + (size_t)L.ch * 16, 0, (row_room - (size_t)L.ch) * 16);
+    if (pool) pool->run(C.bands, fn, &j);
+    else
+        for (int b = 0; b < C.bands; ++b) fn(&j, b);
+    *blocks = j.blocks.load();
     return j.bad.load() ? 1 : 0;
 }
 

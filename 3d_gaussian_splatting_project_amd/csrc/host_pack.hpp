@@ -48,6 +48,28 @@ int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HO
 // Writes the packed map (layout L) at dst; returns 0, or 1 if a label lies outside [-1, bins-2].
 // `pool` may be nullptr (single thread).
 int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst);
+// The COMPACT transfer form of a two-level map (what crosses PCIe for a host map; tiled + coarse layouts only):
+//   [0, table_bytes)                     uint32 first_block[bands]: where the band's mixed cells start in the stream
+//   [table_bytes, +coarse_bytes)         the coarse level exactly as it sits in the pool (padding zeroed)
+//   [stream_off, stream_off + 16*blocks) one 16-byte block (4 rows x 4 pixels, u8 bins) per MIXED 4x4 cell (coarse byte 255:
+//                                        the cell's pixels differ, or it sticks out of the map), band by band in the
+//                                        order the bands' workers reserved room (an atomic counter: the order differs from
+//                                        run to run, the table says where), inside a band cell row by cell row (a band has
+//                                        two), inside a cell row by cell column
+// Uniform cells travel as their coarse byte alone; the GPU rebuilds the full-resolution level (seg_expand_kernel).
+struct CompactLayout {
+    int bands = 0;             // bands of 8 pixel rows
+    size_t table_bytes = 0;    // 256-B aligned pieces
+    size_t coarse_bytes = 0;
+    size_t stream_off = 0;
+    size_t capacity = 0;       // stream_off + room for every cell being mixed
+};
+CompactLayout compact_layout(const MapLayout& L);
+// Packs `seg` into the compact form at rec (capacity bytes), using `scratch` (L.fine_bytes bytes of ordinary memory: the
+// narrowed strips live there for the duration of the call).  *blocks = 16-byte blocks in the stream.
+// Returns 0, or 1 if a label lies outside [-1, bins-2].
+int host_pack_map_compact(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* scratch,
+                          uint8_t* rec, size_t* blocks);
 // out = in, split over the pool (D2H epilogue: pinned -> the caller's pageable array)
 void host_copy(Workers* pool, void* dst, const void* src, size_t bytes);
 // dst[i] = (int)src[i] - 1 (bin -> label), split over the pool (D2H epilogue: the labels cross PCIe as one byte each)

@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -386,6 +387,77 @@ __global__ __launch_bounds__(kBlock) void seg_pack_fused_kernel(PackArgs a) {
         out[a.coarse_off + (long long)(cx >> 4) * a.cstrip_bytes + (cx & 15) + ((long long)cy << 4)] = uniform ? (uint8_t)(rows[0] & 0xffu) : (uint8_t)255;
     }
     if (bad) atomicMin(a.err, a.view[job]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Host maps arrive in the COMPACT form of host_pack.hpp (coarse level + one 16-byte block per mixed 4x4 cell: the PCIe
+// link, not the host pass, is what a run's hand-over waits for, and a segmentation map is mostly uniform cells).  This
+// kernel, queued behind the DMA of a group of maps on a GPU that has nothing else to do while maps are handed over,
+// rebuilds the pool form: one workgroup = one band of 8 pixel rows of one map; a thread takes cells in the stream's
+// order (cell row of the band, cell column), a ballot scan ranks the mixed ones, and every cell is written
+// as four 4-byte rows - its block, or its coarse byte four times over.  The coarse level is copied as it is; every
+// byte of the map's pool stride is written (cells and rows past the map, alignment gaps: 0), so a pool map stays a pure
+// function of the map, which exchange protocol v4 ships.
+// -------------------------------------------------------------------------------------------------
+struct ExpandArgs {
+    const uint8_t* rec[kCompactBatch];  // compact records in the device staging buffer
+    uint8_t* map[kCompactBatch];        // their places in the pool
+    int w, h, strip_bytes, cstrip_bytes, cw, ch, strips;
+    unsigned table_bytes, stream_off, coarse_off, fine_bytes, map_bytes, stride;
+    unsigned max_block;  // last block a record of this geometry can hold, counted from the band's first
+};
+
+__global__ __launch_bounds__(kBlock) void seg_expand_kernel(ExpandArgs a) {
+    __shared__ unsigned wave_total[kBlock / 64];
+    const uint8_t* __restrict__ rec = a.rec[blockIdx.y];
+    uint8_t* __restrict__ map = a.map[blockIdx.y];
+    const int band = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t* __restrict__ coarse = rec + a.table_bytes;
+    const uint4* __restrict__ stream = reinterpret_cast<const uint4*>(rec + a.stream_off) + reinterpret_cast<const uint32_t*>(rec)[band];
+    const int per = a.strips * 4, ncells = per * 2;  // cells per cell row (padded to whole strips); a band has two cell rows
+    unsigned running = 0;  // mixed cells of this band before the current round
+    for (int i0 = 0; i0 < ncells; i0 += kBlock) {
+        const int i = i0 + tid;
+        const bool valid = i < ncells;
+        const int cyl = i >= per ? 1 : 0, cx = i - cyl * per;  // the stream's order: cell row by cell row, then by column
+        const int s = cx >> 2, cc = cx & 3, cy = band * 2 + cyl;
+        const bool cell = valid && cy < a.ch && cx < a.cw;
+        const unsigned cb = cell ? coarse[(size_t)(cx >> 4) * a.cstrip_bytes + (cx & 15) + ((size_t)cy << 4)] : 0u;
+        const bool mixed = cell && cb == 255u;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mixed);
+        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();  // the previous round's totals have been read
+        if (lane == 0) wave_total[wv] = (unsigned)__popcll(m);
+        __syncthreads();
+        unsigned before = running;
+#pragma unroll
+        for (int k = 0; k < kBlock / 64; ++k) {
+            before += k < wv ? wave_total[k] : 0u;
+            running += wave_total[k];
+        }
+        if (valid) {
+            uint32_t r0, r1, r2, r3;
+            if (mixed) {
+                const uint4 b = stream[min(before + below, a.max_block)];  // (a record is the library's own: the clamp never acts)
+                r0 = b.x, r1 = b.y, r2 = b.z, r3 = b.w;
+            } else {
+                r0 = r1 = r2 = r3 = cb * 0x01010101u;  // a uniform cell; 0 for the cells and rows past the map
+            }
+            uint8_t* o = map + (size_t)s * a.strip_bytes + ((size_t)(band * 8 + cyl * 4) << 4) + cc * 4;
+            *reinterpret_cast<uint32_t*>(o) = r0;
+            *reinterpret_cast<uint32_t*>(o + 16) = r1;
+            *reinterpret_cast<uint32_t*>(o + 32) = r2;
+            *reinterpret_cast<uint32_t*>(o + 48) = r3;
+        }
+    }
+    // the coarse level, verbatim (16-byte pieces dealt over the bands), and the alignment gaps
+    const unsigned cbytes = a.map_bytes - a.coarse_off;  // a multiple of 128
+    for (unsigned j = (unsigned)band * kBlock + tid; j < cbytes / 16; j += gridDim.x * kBlock)
+        reinterpret_cast<uint4*>(map + a.coarse_off)[j] = reinterpret_cast<const uint4*>(coarse)[j];
+    if (band == 0) {
+        for (unsigned j = a.fine_bytes + tid; j < a.coarse_off; j += kBlock) map[j] = 0;
+        for (unsigned j = a.map_bytes + tid; j < a.stride; j += kBlock) map[j] = 0;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1036,6 +1108,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->n_pad = c->sn * c->slabs;
     c->views.clear();
     c->pend_count = 0;  // packed maps of an abandoned run that never went up: forgotten with it
+    c->compact_bytes = 0;
     c->views_dirty = true;
     c->pool_base = nullptr;
     c->seg_used = 0;
@@ -1140,23 +1213,81 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
     if (c->opt_host_pack) {
         const size_t stride = (L.map_bytes + 255) / 256 * 256;
         constexpr int kSlots = kDmaBatch * kDmaGroups;
-        if (c->hring_slot != stride || !c->hring) {  // first map, or a new geometry: re-lay the ring
+        // compact transfer form (host_pack.hpp) whenever the pool form has both levels; else the pool form itself
+        const bool compact = c->opt_host_compact && L.strip_bytes && L.cstrip_bytes;
+        const CompactLayout CL = compact ? compact_layout(L) : CompactLayout{};
+        const size_t slot_bytes = compact ? (CL.capacity + 255) / 256 * 256 : stride;
+        if (c->hring_slot != slot_bytes || !c->hring || c->hring_compact != compact) {  // first map, or a new geometry: re-lay the ring
             if ((rc = vote_flush_pending(c))) return rc;
             for (int g = 0; g < kDmaGroups; ++g) {
                 if (c->hring_busy[g]) GSX_HIP(c, hipEventSynchronize(c->hring_ev[g]));
                 c->hring_busy[g] = false;
                 if (!c->hring_ev[g]) GSX_HIP(c, hipEventCreateWithFlags(&c->hring_ev[g], hipEventDisableTiming));
             }
-            if (c->hring_bytes < stride * kSlots) {
+            if (c->hring_bytes < slot_bytes * kSlots) {
                 if (c->hring) GSX_HIP(c, hipHostFree(c->hring));
                 c->hring = nullptr;
                 c->hring_bytes = 0;
-                GSX_HIP(c, hipHostMalloc(&c->hring, stride * kSlots, hipHostMallocDefault));
-                c->hring_bytes = stride * kSlots;
+                GSX_HIP(c, hipHostMalloc(&c->hring, slot_bytes * kSlots, hipHostMallocDefault));
+                c->hring_bytes = slot_bytes * kSlots;
             }
-            std::memset(c->hring, 0, stride * kSlots);  // the bytes between a map's end and its stride travel too
-            c->hring_slot = stride;
+            if (!compact) std::memset(c->hring, 0, slot_bytes * kSlots);  // the bytes between a map's end and its stride travel too
+            c->hring_slot = slot_bytes;
+            c->hring_compact = compact;
             c->hring_next = 0;
+            c->cgrp = 0;
+            c->grp_recs = 0;
+        }
+        const size_t off = (c->seg_used + 255) / 256 * 256;
+        if (compact) {
+            // records of a group lie back to back (a record is as long as its map has mixed cells): one DMA per group moves
+            // exactly the bytes in use, and a group takes as many records as fit (at most kCompactBatch)
+            const size_t gcap = (size_t)kDmaBatch * slot_bytes;
+            if (c->grp_recs == 0) {
+                if (c->hring_busy[c->cgrp]) {  // the group's previous DMA must have left the buffer
+                    GSX_HIP(c, hipEventSynchronize(c->hring_ev[c->cgrp]));
+                    c->hring_busy[c->cgrp] = false;
+                }
+                c->grp_used = 0;
+            }
+            if (c->h_scratch_cap < L.fine_bytes) {
+                std::free(c->h_scratch);
+                c->h_scratch = nullptr;
+                c->h_scratch_cap = 0;
+                const size_t cap = (L.fine_bytes + 4095) / 4096 * 4096;
+                if (!(c->h_scratch = std::aligned_alloc(4096, cap))) return fail(c, GSX_E_HIP, "vote_view: out of host memory");
+                c->h_scratch_cap = cap;
+            }
+            uint8_t* rec = static_cast<uint8_t*>(c->hring) + (size_t)c->cgrp * gcap + c->grp_used;
+            size_t blocks = 0;
+            if (!(c->opt_ablate & 2) &&  // timing experiment only: the DMA stream without the host pass; results invalid
+                host_pack_map_compact(host_workers(c, seg), seg, seg_dtype, L, c->bins, static_cast<uint8_t*>(c->h_scratch), rec, &blocks))
+                return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
+            if (c->pend_count && (L.w != c->pend_L.w || L.h != c->pend_L.h)) {  // one expansion launch = one geometry
+                if ((rc = vote_flush_pending(c))) return rc;
+            }
+            if (!c->pend_count) {
+                c->pend_group = c->cgrp;
+                c->pend_lo = c->grp_used;
+                c->pend_L = L;
+            }
+            c->pend_rec[c->pend_count] = c->grp_used;
+            c->pend_map[c->pend_count] = off;
+            ++c->pend_count;
+            ++c->grp_recs;
+            c->grp_used += (CL.stream_off + blocks * 16 + 255) / 256 * 256;
+            c->compact_bytes += CL.stream_off + blocks * 16;
+            push_view(c, cam, L, off, img_w, img_h);
+            const bool full = c->grp_recs == kCompactBatch || c->grp_used + slot_bytes > gcap;  // no room for a worst-case record
+            // the last views of the run (as announced to vote_begin) go up one by one: a group waiting for more maps would put
+            // its DMA between the last hand-over and the vote
+            const bool tail = c->total_views - c->first_view - (int)c->views.size() < kDmaBatch;
+            if (tail || full) rc = vote_flush_pending(c);
+            if (full) {
+                c->cgrp = (c->cgrp + 1) % kDmaGroups;
+                c->grp_recs = 0;
+            }
+            return rc;
         }
         const int s = c->hring_next, g = s / kDmaBatch;
         if (s % kDmaBatch == 0 && c->hring_busy[g]) {  // the group's previous DMA must have left the buffer
@@ -1164,9 +1295,8 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
             c->hring_busy[g] = false;
         }
         uint8_t* slot = static_cast<uint8_t*>(c->hring) + (size_t)s * stride;
-        if (host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, slot))
+        if (!(c->opt_ablate & 2) && host_pack_map(host_workers(c, seg), seg, seg_dtype, L, c->bins, slot))
             return fail(c, GSX_E_RANGE, "vote_view: segmentation map holds a label outside [-1, %d]", c->n_classes - 1);
-        const size_t off = (c->seg_used + 255) / 256 * 256;
         if (c->pend_count && off != c->pend_dst + (size_t)c->pend_count * stride) {  // the pool moved on (device maps in between)
             if ((rc = vote_flush_pending(c))) return rc;
         }
@@ -1175,6 +1305,7 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
             c->pend_dst = off;
         }
         ++c->pend_count;
+        c->compact_bytes += stride;
         push_view(c, cam, L, off, img_w, img_h);
         c->hring_next = (s + 1) % kSlots;
         // the last views of the run (as announced to vote_begin) go up one by one: a whole group waiting for its fourth map
@@ -1284,11 +1415,42 @@ int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* 
 // needs the maps on the device.
 int vote_flush_pending(Ctx* c) {
     if (!c->pend_count) return GSX_OK;
+    GSX_HIP(c, hipSetDevice(c->device));
+    if (c->hring_compact) {
+        const int g = c->pend_group;
+        const size_t gcap = (size_t)kDmaBatch * c->hring_slot;
+        GSX_HIP(c, c->cstage.ensure(gcap));
+        const uint8_t* src = static_cast<uint8_t*>(c->hring) + (size_t)g * gcap;
+        if (!(c->opt_ablate & 1))  // timing experiment only (tools/tail_probe.py): the host pass without its DMA; results invalid
+            GSX_HIP(c, hipMemcpyAsync(c->cstage.as<uint8_t>() + c->pend_lo, src + c->pend_lo, c->grp_used - c->pend_lo, hipMemcpyHostToDevice,
+                                      c->stream));
+        GSX_HIP(c, hipEventRecord(c->hring_ev[g], c->stream));
+        c->hring_busy[g] = true;
+        const MapLayout& L = c->pend_L;
+        const CompactLayout CL = compact_layout(L);
+        ExpandArgs a{};
+        for (int k = 0; k < c->pend_count; ++k) {
+            a.rec[k] = c->cstage.as<uint8_t>() + c->pend_rec[k];
+            a.map[k] = c->segpool.as<uint8_t>() + c->pend_map[k];
+        }
+        a.w = L.w, a.h = L.h, a.strip_bytes = L.strip_bytes, a.cstrip_bytes = L.cstrip_bytes, a.cw = L.cw, a.ch = L.ch;
+        a.strips = (L.w + 15) / 16;
+        a.table_bytes = (unsigned)CL.table_bytes, a.stream_off = (unsigned)CL.stream_off, a.coarse_off = (unsigned)L.coarse_off;
+        a.fine_bytes = (unsigned)L.fine_bytes, a.map_bytes = (unsigned)L.map_bytes, a.stride = (unsigned)((L.map_bytes + 255) / 256 * 256);
+        a.max_block = (unsigned)(2 * L.cw - 1);  // a band holds two cell rows
+        if (!c->opt_ablate) {  // (an ablation leaves no valid record to expand)
+            ProfScope ps(c, "seg_expand");
+            hipLaunchKernelGGL(seg_expand_kernel, dim3((unsigned)CL.bands, (unsigned)c->pend_count), dim3(kBlock), 0, c->stream, a);
+            GSX_HIP(c, hipGetLastError());
+        }
+        c->pend_count = 0;
+        return GSX_OK;
+    }
     const int g = c->pend_first / kDmaBatch;
     const size_t bytes = (size_t)c->pend_count * c->hring_slot;
-    GSX_HIP(c, hipSetDevice(c->device));
-    GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + c->pend_dst, static_cast<uint8_t*>(c->hring) + (size_t)c->pend_first * c->hring_slot,
-                              bytes, hipMemcpyHostToDevice, c->stream));
+    if (!(c->opt_ablate & 1))
+        GSX_HIP(c, hipMemcpyAsync(c->segpool.as<uint8_t>() + c->pend_dst, static_cast<uint8_t*>(c->hring) + (size_t)c->pend_first * c->hring_slot,
+                                  bytes, hipMemcpyHostToDevice, c->stream));
     GSX_HIP(c, hipEventRecord(c->hring_ev[g], c->stream));
     c->hring_busy[g] = true;
     c->pend_count = 0;
@@ -1316,6 +1478,10 @@ void vote_release_host(Ctx* c) {
     if (c->hring) (void)hipHostFree(c->hring);
     c->hring = nullptr;
     c->hring_bytes = c->hring_slot = 0;
+    std::free(c->h_scratch);
+    c->h_scratch = nullptr;
+    c->h_scratch_cap = 0;
+    c->cstage.release();
     c->pend_count = 0;
     for (hipEvent_t& e : c->h_ev) {
         if (e) (void)hipEventDestroy(e);
@@ -1346,6 +1512,29 @@ int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes,
     Workers pool(threads > 0 ? threads : 1);
     const int b = host_pack_map(&pool, seg, seg_dtype, L, n_classes + 1, out);
     if (bad) *bad = b;
+    return GSX_OK;
+}
+
+// test hook, host only: the compact transfer form of one map (host_pack.hpp), as gsx_vote_view writes it into the pinned ring
+int debug_host_pack_compact(const void* seg, int seg_dtype, int w, int h, int n_classes, int threads, uint8_t* out, int64_t out_cap,
+                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad) {
+    if (!seg || w < 1 || h < 1 || w > 65535 || h > 65535 || n_classes < 1 || n_classes > 254 || seg_dtype < 0 || seg_dtype > 3 || !bytes)
+        return fail(nullptr, GSX_E_INVALID, "debug_host_pack_compact: bad arguments");
+    const MapLayout L = map_layout(w, h, true, true);
+    const CompactLayout CL = compact_layout(L);
+    if (table_bytes) *table_bytes = (int64_t)CL.table_bytes;
+    if (stream_off) *stream_off = (int64_t)CL.stream_off;
+    *bytes = (int64_t)CL.capacity;
+    if (!out) return GSX_OK;
+    if (out_cap < (int64_t)CL.capacity) return fail(nullptr, GSX_E_INVALID, "debug_host_pack_compact: output buffer too small");
+    void* scratch = std::aligned_alloc(4096, (L.fine_bytes + 4095) / 4096 * 4096);
+    if (!scratch) return fail(nullptr, GSX_E_HIP, "debug_host_pack_compact: out of memory");
+    Workers pool(threads > 0 ? threads : 1);
+    size_t blocks = 0;
+    const int b = host_pack_map_compact(&pool, seg, seg_dtype, L, n_classes + 1, static_cast<uint8_t*>(scratch), out, &blocks);
+    std::free(scratch);
+    if (bad) *bad = b;
+    *bytes = (int64_t)(CL.stream_off + blocks * 16);
     return GSX_OK;
 }
 

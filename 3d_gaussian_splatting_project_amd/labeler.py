@@ -269,6 +269,10 @@ class Context:
     def vote_pool_bytes(self):
         return int(self._lib.gsx_vote_pool_bytes(self.h))
 
+    def vote_link_bytes(self):
+        """bytes of host maps sent over PCIe since vote_begin (compact records, or maps in pool form)"""
+        return int(self._lib.gsx_vote_link_bytes(self.h))
+
     def vote_import(self, part_views, part_offsets, blobs, pool_all_ptr, pool_all_bytes):
         pv = np.ascontiguousarray(part_views, np.int32)
         po = np.ascontiguousarray(part_offsets, np.int64)

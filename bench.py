@@ -376,7 +376,9 @@ def main():
         raw = float(sum(s.nbytes for s in host_segs))
         side["host_ingest"] = {"ms_per_map_submit": round(t_submit / V * 1e3, 4), "ms_per_map_done": round(t_all / V * 1e3, 4),
                                "effective_GBps_of_int32_maps": round(raw / t_all / 1e9, 2), "int32_bytes": int(raw),
-                               "host_threads": ctx.host_threads()}
+                               "host_threads": ctx.host_threads(), "pcie_bytes": ctx.vote_link_bytes(),
+                               "pcie_note": "bytes of the maps that crossed the link: the compact form (coarse level + the 16-byte blocks of "
+                                            "the 4x4 cells whose pixels differ), expanded to the two-level pool form on the GPU"}
         ctx.vote_finalize(out=labels_buf)
 
     # ---- CPU baseline: the oracle (C port of the reference loop) on bounded samples of the same workload ----------------

@@ -93,6 +93,10 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               pixel boundary (and any non-finite case) take the exact IEEE divisions.  Bit-identical
  *                               (tested on 7e7 pairs and at pixel boundaries) but measured 1 % SLOWER: 15 fewer fp64
  *                               instructions per visible pair, yet both axes are evaluated before the first early-out
+ *   "host_compact" (default 1)  host maps (gsx_vote_view) cross PCIe as their coarse level plus the 16-byte blocks of the
+ *                               mixed 4x4 cells only, and a kernel behind the DMA rebuilds the pool form (the link, not
+ *                               the host pass, is what the hand-over of 200 1080p maps waits for); 0 = the pool form
+ *                               itself crosses the link.  Same pool bytes, same labels
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
@@ -260,6 +264,9 @@ int gsx_vote_export(gsx_ctx* ctx, int64_t reserve_bytes, void* blobs_out, void**
 /* bytes of this rank's pool in use (what gsx_vote_export reports), without touching the stream: host maps that are packed
  * but whose grouped DMA has not been queued yet are counted; gsx_vote_export queues them */
 int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx);
+/* statistics: bytes of HOST maps (gsx_vote_view) sent over PCIe since gsx_vote_begin - compact records (option
+ * "host_compact") or maps in pool form */
+int64_t gsx_vote_link_bytes(const gsx_ctx* ctx);
 /* part r contributed part_views[r] views (blobs in part order) whose maps start at byte part_offsets[r] of
  * pool_all_dev (pool_all_bytes long; caller-owned, must stay alive and unchanged until the labels have been fetched).
  * Replaces the views staged so far; global view order = part order.  Blobs are validated against the pool size. */
@@ -362,6 +369,13 @@ int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad);
+/* test hook, host only: the COMPACT transfer form in which gsx_vote_view sends a two-level map over PCIe (option
+ * "host_compact", default 1): uint32 first_block[bands of 8 rows] | the coarse level as in the pool | one 16-byte block
+ * (4 rows x 4 pixels) per mixed 4x4 cell, band by band (order of the bands' workers: the table says where), inside a band
+ * by cell row, then cell column.  out == NULL: *bytes = worst-case size; otherwise *bytes = bytes in use. */
+int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t threads,
+                                uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off,
+                                int32_t* bad);
 /* test hook, host only: `runs` fork-joins of pseudo-random size (1..max_parts parts) on ONE worker pool of `threads` threads;
  * returns how many parts did not run exactly once (0 = the pool is sound), -1 if the pool could not be created */
 int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_parts);

@@ -436,6 +436,43 @@ def pack_map_numpy(seg, n_classes):
     return out, coarse_off
 
 
+def expand_compact_numpy(rec, w, h, table_bytes, stream_off):
+    """The pool form of a map from its COMPACT transfer form (csrc/host_pack.hpp; what seg_expand_kernel does on the GPU),
+    restated in numpy: -> bytes equal to pack_map_numpy(seg)[0]."""
+    rec = np.asarray(rec, np.uint8)
+    strips, bands = (w + 15) // 16, (h + 7) // 8
+    strip_bytes = bands * 128
+    fine_bytes = strip_bytes * strips
+    cw, ch = (w + 3) // 4, (h + 3) // 4
+    cstrip_bytes = (ch + 7) // 8 * 128
+    coarse_off = (fine_bytes + 255) // 256 * 256
+    cbytes = cstrip_bytes * ((cw + 15) // 16)
+    out = np.zeros(coarse_off + cbytes, np.uint8)
+    coarse = rec[table_bytes:table_bytes + cbytes]
+    out[coarse_off:] = coarse
+    table = rec[:4 * bands].view(np.uint32)
+    stream = rec[stream_off:]
+    for b in range(bands):
+        k = int(table[b])
+        for cyl in range(2):                                       # the stream's order: cell row, then cell column
+            cy = 2 * b + cyl
+            if cy >= ch:
+                continue                                           # rows past the map stay 0
+            for cx in range(cw):
+                s, c = cx >> 2, cx & 3
+                base = s * strip_bytes + (8 * b + 4 * cyl) * 16 + 4 * c
+                cb = coarse[(cx >> 4) * cstrip_bytes + (cx & 15) + cy * 16]
+                if cb == 255:
+                    blk = stream[16 * k:16 * k + 16]
+                    k += 1
+                    for r in range(4):
+                        out[base + 16 * r:base + 16 * r + 4] = blk[4 * r:4 * r + 4]
+                else:
+                    for r in range(4):
+                        out[base + 16 * r:base + 16 * r + 4] = cb
+    return out
+
+
 def unpack_map_numpy(packed, w, h):
     """Inverse of pack_map_numpy's full-resolution level: int32 labels (h, w)."""
     strip = (h + 7) // 8 * 128

@@ -33,6 +33,7 @@ with gsx.Context(0) as c:
                 "xcd_swizzle": int(rng.choice([0, 1, 4, 32])), "fast_div": int(rng.random() < 0.3), "lds_batch": int(rng.random() < 0.2)}
         opts["host_threads"] = int(rng.choice([1, 3, 16]))
         opts["labels_u8"] = int(rng.random() < 0.8)
+        opts["host_compact"] = int(rng.random() < 0.7)
         for k, v in opts.items():
             c.set_option(k, v)
         spread = float(rng.choice([0.3, 2.0, 8.0, 40.0]))

@@ -86,7 +86,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
                  {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
-                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
+                 {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"host_compact": 0}, {"host_compact": 0, "host_threads": 3}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
                  {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
             for k, v in opts.items():
@@ -622,6 +622,49 @@ def test_device_map_range_error_is_reported_with_the_labels(ctx, gsx):
     ctx.vote_begin(10, 0, 2)                    # a new run starts clean
     ctx.vote_view(cam, good)
     assert set(ctx.vote_finalize().tolist()) <= {3, -1}
+
+
+def test_host_maps_cross_pcie_in_compact_form(gsx):
+    """gsx_vote_view: the workers write the compact form (coarse level + the mixed cells' blocks) into the pinned ring, one DMA
+    per group moves the records, seg_expand_kernel rebuilds the pool form.  The pool must hold exactly the bytes of the numpy
+    restatement of the layout - ragged sizes, maps smaller than a cell, groups of 1-4 maps and the one-by-one tail of a run,
+    changing geometry inside a run - and the same bytes as with the pool form crossing the link (host_compact = 0)."""
+    dist = importlib.import_module("3d_gaussian_splatting_project_amd.dist")
+    rng = np.random.default_rng(5)
+    cam = scene.make_cameras(1, 64, 48, convention="w2c")[0]
+
+    def make(w, h, p_noise):
+        blocks = rng.integers(-1, 150, size=((h + 7) // 8, (w + 7) // 8), dtype=np.int32)   # 8x8 blocks: uniform cells exist
+        sgm = np.repeat(np.repeat(blocks, 8, 0), 8, 1)[:h, :w].copy()
+        noise = rng.random((h, w)) < p_noise
+        sgm[noise] = rng.integers(-1, 150, size=int(noise.sum()))
+        return sgm
+
+    def pool_of(segs, compact, total=None):
+        with gsx.Context(0) as c:
+            c.set_option("host_compact", compact)
+            c.upload_positions(np.zeros((4, 3), np.float32))
+            c.vote_begin(150, 0, total or len(segs))
+            for sgm in segs:
+                c.vote_view(cam, sgm, (sgm.shape[1], sgm.shape[0]))
+            ptr, used, _ = c.vote_export()
+            c.synchronize()
+            return dist.device_bytes_tensor(ptr, used, 0).cpu().numpy().copy()
+
+    def check(segs, total=None):
+        pools = [pool_of(segs, k, total) for k in (1, 0)]
+        assert np.array_equal(pools[0], pools[1])
+        off = 0
+        for sgm in segs:
+            ref, _ = oracle.pack_map_numpy(sgm, 150)
+            assert np.array_equal(pools[0][off:off + ref.size], ref), sgm.shape
+            off += (ref.size + 255) // 256 * 256
+
+    for (w, h) in ((1, 1), (3, 5), (4, 4), (16, 8), (17, 9), (61, 35), (64, 64), (65, 33), (322, 181), (1920, 1080)):
+        for V in ((1, 6) if w * h < 100_000 else (5,)):
+            check([make(w, h, (0.0, 0.02, 0.6)[v % 3]) for v in range(V)])
+    check([make(64, 48, 0.02), make(64, 48, 0.5), make(61, 35, 0.02), make(64, 48, 0.0), make(128, 96, 0.1), make(128, 96, 0.1),
+           make(128, 96, 0.9), make(128, 96, 0.0), make(128, 96, 0.3), make(16, 16, 0.0)], total=40)   # geometry changes, no tail
 
 
 def test_labels_leave_the_device_as_bytes(gsx):
