@@ -385,6 +385,8 @@ struct PackJob {
     unsigned bins;
     uint8_t* dst;     // full-resolution level (strips)
     uint8_t* coarse;  // coarse level (plain form: dst + L.coarse_off)
+    int nseg = 1, seg_strips = 0;  // a unit = one band x one segment of seg_strips strips (map_segments)
+    int units = 0, group = 1;      // a part of the fork-join = `group` consecutive units
     // compact form only
     uint32_t* table = nullptr;
     uint8_t* stream = nullptr;
@@ -400,25 +402,28 @@ struct PackJob {
 // reads at twice the rate of eight row streams walked strip by strip in lock step.  The 16-byte pieces go to the strips'
 // lines (strip_bytes apart), which stay in L1/L2 for the 8 rows of the band; the coarse bytes are made from them at the end.
 template <typename T, unsigned ADD>
-static void pack_band_tiled(PackJob* j, int band) {
+static void pack_band_tiled(PackJob* j, int part) {
     const MapLayout L = j->L;  // by value: the u8 stores below may alias anything reached through a pointer
     const unsigned bins = j->bins;
     uint8_t* const dst = j->dst;
     const T* seg = static_cast<const T*>(j->seg);
+    const int band = part / j->nseg, sgm = part % j->nseg;
     const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
     const int strips = (L.w + 15) / 16, full = L.w / 16;
+    const int s0 = sgm * j->seg_strips, s1 = s0 + j->seg_strips < strips ? s0 + j->seg_strips : strips;  // this part's strips
+    const int nfull = (full < s1 ? full : s1) - s0;  // whole strips among them
     unsigned bad = 0;
     for (int y = y0; y < y1; ++y) {
         const T* row = seg + (size_t)y * L.w;
         uint8_t* o = dst + (size_t)y * 16;  // row y of strip 0
-        if (full) bad |= rows16<T, ADD>(row, 16, full, bins, o, (size_t)L.strip_bytes);
-        if (full < strips) {  // ragged last strip: columns past the map hold bin 0
+        if (nfull > 0) bad |= rows16<T, ADD>(row + (size_t)s0 * 16, 16, nfull, bins, o + (size_t)s0 * L.strip_bytes, (size_t)L.strip_bytes);
+        if (full < strips && s1 == strips) {  // ragged last strip: columns past the map hold bin 0
             uint8_t* e = o + (size_t)full * L.strip_bytes;
             std::memset(e, 0, 16);
             bad |= narrow_n<T, ADD>(row + (size_t)full * 16, L.w - full * 16, bins, e);
         }
     }
-    for (int s = 0; s < strips; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const int x0 = s * 16;
         const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
         uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)y0 * 16;
@@ -460,16 +465,16 @@ static void pack_band_tiled(PackJob* j, int band) {
         // compare + movemask.
         constexpr int kMaxCs = 1024;  // coarse strips of a 65535-pixel row
         uint16_t masks[2][kMaxCs];
-        const int ncs = (L.cw + 15) >> 4;
+        const int cs0 = s0 >> 2, cs1 = (s1 + 3) >> 2;  // this part's coarse strips (a segment is a whole number of them)
         uint32_t n = 0;
         int rows_here = 0;
         for (int cyl = 0; cyl < 2; ++cyl) {
             const int cy = band * 2 + cyl;
             if (cy >= L.ch) break;
             rows_here = cyl + 1;
-            if (L.cw & 15)  // the cells past the map's last cell column: defined bytes (the level goes into the pool as it is)
+            if ((L.cw & 15) && s1 == strips)  // the cells past the map's last cell column: defined bytes (the level goes into the pool as it is)
                 std::memset(j->coarse + (size_t)(L.cw >> 4) * L.cstrip_bytes + (size_t)cy * 16 + (L.cw & 15), 0, (size_t)(16 - (L.cw & 15)));
-            for (int cs = 0; cs < ncs; ++cs) {
+            for (int cs = cs0; cs < cs1; ++cs) {
                 const uint8_t* co = j->coarse + (size_t)cs * L.cstrip_bytes + (size_t)cy * 16;
                 unsigned m;
 #if defined(__x86_64__)
@@ -483,11 +488,11 @@ static void pack_band_tiled(PackJob* j, int band) {
             }
         }
         const uint32_t first = n ? j->blocks.fetch_add(n, std::memory_order_relaxed) : 0u;
-        j->table[band] = first;
+        j->table[part] = first;
         uint8_t* out = j->stream + (size_t)first * 16;
         for (int cyl = 0; cyl < rows_here && n; ++cyl) {
             const uint8_t* rows = dst + (size_t)(y0 + cyl * 4) * 16;  // row 4*cyl of the band in strip 0
-            for (int cs = 0; cs < ncs; ++cs) {
+            for (int cs = cs0; cs < cs1; ++cs) {
                 for (unsigned m = masks[cyl][cs]; m; m &= m - 1) {
                     const int cx = cs * 16 + __builtin_ctz(m);
                     const uint8_t* q = rows + (size_t)(cx >> 2) * L.strip_bytes + (cx & 3) * 4;  // rows 16 bytes apart
@@ -515,10 +520,29 @@ static void pack_band_rows(PackJob* j, int band) {  // row-major u8 map ("seg_ti
 }
 
 template <typename T, unsigned ADD>
-static void pack_part(void* arg, int band) {
+static void pack_part(void* arg, int part) {
     PackJob* j = static_cast<PackJob*>(arg);
-    if (j->L.strip_bytes) pack_band_tiled<T, ADD>(j, band);
-    else pack_band_rows<T, ADD>(j, band);
+    const int lo = part * j->group, hi = lo + j->group < j->units ? lo + j->group : j->units;
+    for (int u = lo; u < hi; ++u) {
+        if (j->L.strip_bytes) pack_band_tiled<T, ADD>(j, u);
+        else pack_band_rows<T, ADD>(j, u);
+    }
+}
+
+// A band of 8 rows is cut into segments of whole coarse strips (64 pixel columns) so that a 1080p map is ~270 parts, not
+// 135: with 16 threads the last parts of a call decide how long it takes, and a part should be a small share of a thread's work.
+static std::atomic<int> g_parts_target{1};  // measured: cutting bands into column segments (256 -> 270 parts per 1080p map) makes the hand-over 12 % SLOWER
+static std::atomic<int> g_band_group{1};
+void set_host_band_group(int bands) { g_band_group.store(bands < 1 ? 1 : bands > 64 ? 64 : bands); }
+void set_host_parts_target(int parts) { g_parts_target.store(parts < 1 ? 1 : parts); }
+void map_segments(const MapLayout& L, int* nseg, int* seg_strips) {
+    const int strips = (L.w + 15) / 16, bands = (L.h + 7) / 8;
+    int n = L.strip_bytes ? (g_parts_target.load(std::memory_order_relaxed) + bands - 1) / bands : 1;
+    if (n > 4) n = 4;
+    int per = ((strips + n - 1) / n + 3) / 4 * 4;  // whole coarse strips
+    if (per < 4) per = 4;
+    *seg_strips = per;
+    *nseg = (strips + per - 1) / per;
 }
 
 int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst) {
@@ -532,7 +556,10 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
                              : seg_dtype == 1 ? pack_part<int64_t, 1u>
                              : seg_dtype == 2 ? pack_part<uint8_t, 0u>
                                               : pack_part<uint8_t, 1u>;
-    const int bands = (L.h + 7) / 8;
+    map_segments(L, &j.nseg, &j.seg_strips);
+    const int bands = ((L.h + 7) / 8 * j.nseg + g_band_group.load() - 1) / g_band_group.load();  // parts
+    j.units = (L.h + 7) / 8 * j.nseg;
+    j.group = g_band_group.load();
     // the coarse level's padding (cell rows / columns past the map) is never read; zero it so that a packed map is a
     // function of the map alone (the all-gather of protocol v4 ships these bytes)
     if (L.cstrip_bytes) std::memset(dst + L.coarse_off, 0, L.map_bytes - L.coarse_off);
@@ -546,8 +573,10 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
 
 CompactLayout compact_layout(const MapLayout& L) {
     CompactLayout C;
+    map_segments(L, &C.nseg, &C.seg_strips);
     C.bands = (L.h + 7) / 8;
-    C.table_bytes = ((size_t)C.bands * 4 + 255) / 256 * 256;
+    C.parts = C.bands * C.nseg;
+    C.table_bytes = ((size_t)C.parts * 4 + 255) / 256 * 256;
     C.coarse_bytes = (L.map_bytes - L.coarse_off + 255) / 256 * 256;
     C.stream_off = C.table_bytes + C.coarse_bytes;
     C.capacity = C.stream_off + (size_t)L.cw * (size_t)L.ch * 16;
@@ -565,19 +594,24 @@ int host_pack_map_compact(Workers* pool, const void* seg, int seg_dtype, const M
     j.coarse = rec + C.table_bytes;
     j.table = reinterpret_cast<uint32_t*>(rec);
     j.stream = rec + C.stream_off;
+    j.nseg = C.nseg;
+    j.seg_strips = C.seg_strips;
     void (*fn)(void*, int) = seg_dtype == 0   ? pack_part<int32_t, 1u>
                              : seg_dtype == 1 ? pack_part<int64_t, 1u>
                              : seg_dtype == 2 ? pack_part<uint8_t, 0u>
                                               : pack_part<uint8_t, 1u>;
-    std::memset(rec + (size_t)C.bands * 4, 0, C.table_bytes - (size_t)C.bands * 4);
+    std::memset(rec + (size_t)C.parts * 4, 0, C.table_bytes - (size_t)C.parts * 4);
     // cell rows past the map (a coarse strip has room for a multiple of 8): defined bytes, like the cell columns past the
     // map that the bands clear - the level goes into the pool as it is
     const size_t row_room = (size_t)L.cstrip_bytes / 16;
     for (int cs = 0; cs * 16 < L.cw && row_room > (size_t)L.ch; ++cs)
         std::memset(j.coarse + (size_t)cs * L.cstrip_bytes + (size_t)L.ch * 16, 0, (row_room - (size_t)L.ch) * 16);
-    if (pool) pool->run(C.bands, fn, &j);
+    j.units = C.parts;
+    j.group = g_band_group.load();
+    const int nparts = (C.parts + j.group - 1) / j.group;
+    if (pool) pool->run(nparts, fn, &j);
     else
-        for (int b = 0; b < C.bands; ++b) fn(&j, b);
+        for (int b = 0; b < nparts; ++b) fn(&j, b);
     *blocks = j.blocks.load();
     return j.bad.load() ? 1 : 0;
 }

@@ -660,9 +660,10 @@ def test_host_maps_cross_pcie_in_compact_form(gsx):
             assert np.array_equal(pools[0][off:off + ref.size], ref), sgm.shape
             off += (ref.size + 255) // 256 * 256
 
-    for (w, h) in ((1, 1), (3, 5), (4, 4), (16, 8), (17, 9), (61, 35), (64, 64), (65, 33), (322, 181), (1920, 1080)):
-        for V in ((1, 6) if w * h < 100_000 else (5,)):
+    for (w, h) in ((1, 1), (3, 5), (4, 4), (16, 8), (17, 9), (61, 35), (64, 64), (65, 33), (322, 181), (1280, 40), (1920, 1080)):
+        for V in ((1, 6) if w * h < 100_000 else (5,)):              # (1280, 40), (1920, 1080): bands cut into several parts
             check([make(w, h, (0.0, 0.02, 0.6)[v % 3]) for v in range(V)])
+    check([make(322, 181, 0.02) for _ in range(37)])                   # several full groups of records, then the one-by-one tail
     check([make(64, 48, 0.02), make(64, 48, 0.5), make(61, 35, 0.02), make(64, 48, 0.0), make(128, 96, 0.1), make(128, 96, 0.1),
            make(128, 96, 0.9), make(128, 96, 0.0), make(128, 96, 0.3), make(16, 16, 0.0)], total=40)   # geometry changes, no tail
 
