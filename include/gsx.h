@@ -163,10 +163,11 @@ int gsx_project_all(gsx_ctx* ctx, const gsx_camera* cam, int32_t* x, int32_t* y)
  * counters: <= 65535).  Single GPU: first_view = 0, total_views = number of views (upper bound ok). */
 int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t total_views);
 /* seg: HOST pointer, seg_h x seg_w row-major.  img_w,img_h: the PIL image size (dls.py:261-263).
- * The map is read during the call (worker threads narrow it to the u8 on-device form inside pinned memory and
- * check the label range: GSX_E_RANGE fails THIS call and stages nothing); the DMA into the pool is asynchronous
- * (one copy per group of 4 consecutive maps: an enqueue costs ~6 us of host time) and nothing is synchronised: 200 calls
- * cost the host pass over the maps, ~2.2 MB of PCIe traffic per 1080p map.
+ * The map is read during the call (worker threads narrow it to u8 bins and check the label range: GSX_E_RANGE fails THIS
+ * call and stages nothing) and written into pinned memory in a compact transfer form - the 4x4-coarsened level plus one
+ * 16-byte block per cell whose pixels differ (option "host_compact"); one asynchronous DMA per group of up to 16 maps moves
+ * the records and a kernel queued behind it rebuilds the two-level on-device map.  Nothing is synchronised: 200 calls
+ * cost the host pass over the maps (the link carries ~0.3 MB per 1080p map of an ordinary segmentation, 2.2 MB at worst).
  * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool.
  * Option "host_pack" = 0 selects the alternative hand-over: the workers only copy the raw map into pinned memory, the raw
  * bytes cross PCIe (4x as many for int32) and the fused kernel of gsx_vote_view_device packs them; the range check is
