@@ -72,6 +72,16 @@ def parse():
     return ap.parse_args()
 
 
+def _cpu_throttle():
+    """(periods, throttled periods, throttled microseconds) of this process's cgroup, or None: the GPU box gives a rank a CPU
+    quota; a step that ran into it was frozen for the rest of a 100 ms scheduler period."""
+    try:
+        kv = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(kv["nr_periods"]), int(kv["nr_throttled"]), int(kv["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_segmaps(scene, torch, device, H, W, classes, seeds, cell):
     """Voronoi class maps (400 sites, classes U{-1..C-1}) as HOST int32 arrays.  cell > 1: the package's numpy/scipy
     generator.  cell == 1 (pixel-accurate): the same construction evaluated on the GPU (2 M pixels x 400 sites per
@@ -259,11 +269,16 @@ def main():
     ctx.vote_culled(reset=True)
     if not args.no_profile:
         ctx.profile(True)
+    thr0 = _cpu_throttle()
+    step_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)   # host-side view of each step (the LAST one ends at the fence below)
     fence()
     elapsed = time.perf_counter() - t0
+    thr1 = _cpu_throttle()
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -457,6 +472,10 @@ def main():
                        "rehearsal": "N > 1 code path with a ONE-rank RCCL group (GSX_DIST_FORCE_COLLECTIVES=1)" if rehearsal else None,
                        "bound_to_gpu_numa_node": None if bound is None else f"{len(bound)} CPUs",
                        "setup_seconds": round(setup_s, 1),
+                       "step_ms_median_min_max": [round(float(np.median(step_ms)), 3), round(min(step_ms), 3), round(max(step_ms), 3)],
+                       "cpu_quota_throttling_in_timed_region": None if thr0 is None or thr1 is None else
+                       {"scheduler_periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1],
+                        "throttled_ms": round((thr1[2] - thr0[2]) / 1e3, 1)},
                        "exchanged_labels_equal_single_gpu_vote": labels_check},
             "roofline": roofline,
             "cpu_baseline": cpu,
