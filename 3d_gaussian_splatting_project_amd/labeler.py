@@ -98,6 +98,7 @@ class Context:
         check(self._lib.gsx_vote_begin(self.h, n_classes, first_view, total_views), self.h)
 
     _TORCH_DT = {"torch.int32": _lib.GSX_SEG_I32, "torch.int64": _lib.GSX_SEG_I64, "torch.uint8": _lib.GSX_SEG_U8_LABELS}
+    _NP_DT = {np.dtype(np.int32): _lib.GSX_SEG_I32, np.dtype(np.int64): _lib.GSX_SEG_I64, np.dtype(np.uint8): _lib.GSX_SEG_U8_LABELS}
 
     def vote_view(self, camera, seg_map, image_size=None, packed_u8=False):
         """seg_map: 2-D int array of labels (-1..n_classes-1; any integer dtype, as the reference accepts) on the host,
@@ -105,7 +106,7 @@ class Context:
         packed_u8: a uint8 map already holds label+1 (0 = label -1), the library's own compact form.
         Host maps are range-checked here (ValueError); device maps when the labels are fetched."""
         cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
-        if hasattr(seg_map, "data_ptr"):  # torch tensor on the device
+        if type(seg_map) is not np.ndarray and hasattr(seg_map, "data_ptr"):  # torch tensor on the device
             t = seg_map.contiguous()
             h, w = t.shape
             if not t.is_cuda:
@@ -120,20 +121,26 @@ class Context:
             check(self._lib.gsx_vote_view_device(self.h, C.byref(cam), t.data_ptr(), dt, w, h, int(iw), int(ih)), self.h)
             self._keep_alive.append(t)   # the pack kernel runs asynchronously on the ctx stream
             return
-        seg = np.asarray(seg_map)
+        # (this runs once per view, 200 times in the 10 ms of a run: the usual case - a contiguous int32 / int64 / uint8 array -
+        # takes the short way through, ~1.5 us of Python instead of 3)
+        seg = seg_map if type(seg_map) is np.ndarray else np.asarray(seg_map)
         if seg.ndim != 2:
             raise ValueError("seg_map must be 2-D")
-        if seg.dtype == np.int64:
-            dt = _lib.GSX_SEG_I64
-        elif seg.dtype == np.uint8:
-            dt = _lib.GSX_SEG_U8 if packed_u8 else _lib.GSX_SEG_U8_LABELS
-        else:
+        dt = self._NP_DT.get(seg.dtype)
+        if dt is None:
             seg = seg.astype(np.int32, copy=False)
             dt = _lib.GSX_SEG_I32
-        seg = np.ascontiguousarray(seg)
+        elif packed_u8 and dt == _lib.GSX_SEG_U8_LABELS:
+            dt = _lib.GSX_SEG_U8
+        if not seg.flags.c_contiguous:
+            seg = np.ascontiguousarray(seg)
         h, w = seg.shape
-        iw, ih = image_size if image_size is not None else (w, h)
-        check(self._lib.gsx_vote_view(self.h, C.byref(cam), seg.ctypes.data, dt, w, h, int(iw), int(ih)), self.h)
+        iw, ih = (w, h) if image_size is None else (int(image_size[0]), int(image_size[1]))
+        try:
+            ptr = C.addressof(C.c_char.from_buffer(seg))   # 3x cheaper than seg.ctypes.data
+        except (TypeError, ValueError):                    # a read-only or empty array
+            ptr = seg.ctypes.data
+        check(self._lib.gsx_vote_view(self.h, C.byref(cam), ptr, dt, w, h, iw, ih), self.h)
 
     def vote_views_device(self, cameras, seg_tensors, image_size=None, packed_u8=False):
         """Several device-resident maps of one shape and dtype in one call (gsx_vote_views_device: 16 maps per kernel
