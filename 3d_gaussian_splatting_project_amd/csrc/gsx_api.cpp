@@ -194,6 +194,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;
     else if (k == "host_band_group") gsx::set_host_band_group((int)value);
+    else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);
     else if (k == "host_parts") {  // process-wide; between runs only (a group of pending records is expanded with one cut)
         if (c->pend_count) return gsx::fail(c, GSX_E_STATE, "set_option host_parts: maps are pending");
         gsx::set_host_parts_target((int)value);

@@ -69,7 +69,8 @@ struct CompactLayout {
 CompactLayout compact_layout(const MapLayout& L);
 void map_segments(const MapLayout& L, int* nseg, int* seg_strips);  // how the packers cut a band of a tiled map into parts
 void set_host_band_group(int bands);     // process-wide: consecutive bands one part of the fork-join takes (default 1)
-void set_host_parts_target(int parts);  // process-wide: parts per map the cut aims for (default 256; 1 = one part per band)
+void set_host_parts_target(int parts);
+void set_host_prefetch(int bytes);       // process-wide: how far ahead the narrowing loops prefetch the map (default 8 KB)  // process-wide: parts per map the cut aims for (default 256; 1 = one part per band)
 // Packs `seg` into the compact form at rec (capacity bytes), using `scratch` (L.fine_bytes bytes of ordinary memory: the
 // narrowed strips live there for the duration of the call).  *blocks = 16-byte blocks in the stream.
 // Returns 0, or 1 if a label lies outside [-1, bins-2].

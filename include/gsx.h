@@ -381,7 +381,8 @@ int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, i
 /* test / tuning hook, process-wide, between runs only: how the host packers cut a map into the parts of their fork-join.
  * parts_target (default 1): a band of 8 pixel rows is cut into column segments until a map has about that many parts
  * (options "host_parts"); band_group (default 1): consecutive bands one part takes ("host_band_group").  Both measured
- * slower than one band per part on the GPU box; results never change. */
+ * slower than one band per part on the GPU box; results never change.  Option "host_prefetch"
+ * (default 8192): bytes the narrowing loops prefetch ahead of themselves (NTA hint; a negative value selects T0). */
 void gsx_debug_host_cut(int32_t parts_target, int32_t band_group);
 /* test hook, host only: `runs` fork-joins of pseudo-random size (1..max_parts parts) on ONE worker pool of `threads` threads;
  * returns how many parts did not run exactly once (0 = the pool is sound), -1 if the pool could not be created */
