@@ -41,15 +41,22 @@ MapLayout map_layout(int w, int h, bool tiled, bool coarse) {
 }
 
 // ---- worker pool ---------------------------------------------------------------------------------------------------
-// Fork-join without a SHARED counter on the hot path: thread t owns the contiguous parts [parts*t/T, parts*(t+1)/T),
-// claims them one by one from a counter on its own cache line, and only when its share is done helps the others
-// (a thread that shares its core, reads remote memory or was descheduled would otherwise hold the whole call up).
-// Every thread reports through its own line.  (One shared `next part` counter next to the flag the idle workers poll cost
-// 0.3 ms per call on a 2-socket EPYC: every fetch_add fought the pollers for the line.)  Placement: see below.
+// Fork-join whose cost is a handful of cache-line transfers (a 1080p map is packed in ~30 us, 200 times per run: round 2's
+// first pool spent 3.5-4.4 us per call forking and joining, 10 % of the hand-over):
+//   fork   the caller writes the job (one line) and bumps `generation` (the one line the idle workers poll).  Nothing per
+//          worker is written: thread t owns the contiguous parts [parts*t/T, parts*(t+1)/T) and every thread derives any
+//          thread's bounds itself.
+//   claim  a thread's next unclaimed part lives in a 64-bit word on the thread's own line, tagged with the generation:
+//          (generation << 32) | next.  A stale tag means "nothing claimed yet in this run", so nobody has to reset the
+//          words; owner and helpers claim with the same compare-and-swap.  A thread works through its own share first, then
+//          helps the others (a thread that shares its core, reads remote memory or was descheduled would otherwise hold the
+//          whole call up).
+//   join   every worker decrements one counter (a line of its own, touched once per worker and run) when it has nothing
+//          left to claim; the caller spins on that line only.
+// (One shared `next part` counter next to the flag the idle workers poll cost 0.3 ms per call on a 2-socket EPYC: every
+// fetch_add fought the pollers for the line.)  Placement: see below.
 struct alignas(64) Slot {
-    std::atomic<uint64_t> done{0};  // generation this thread has finished
-    std::atomic<int> next{0};       // next unclaimed part of this thread's share
-    int end = 0;                    // one past the share's last part
+    std::atomic<uint64_t> claim{0};  // (generation << 32) | next unclaimed part of this thread's share
 };
 
 struct Workers::Impl {
@@ -57,28 +64,38 @@ struct Workers::Impl {
     std::mutex m;
     std::condition_variable cv;
     alignas(64) std::atomic<uint64_t> generation{0};  // bumped once per run(); its own line: polled by every idle worker
-    alignas(64) int parts = 0;
+    alignas(64) int parts = 0;                        // the job: written before the bump, read after it
     void (*fn)(void*, int) = nullptr;
     void* arg = nullptr;
-    int nthreads = 1;
+    alignas(64) std::atomic<int> remaining{0};        // workers that have not finished the current run
+    alignas(64) int nthreads = 1;
     std::atomic<bool> stop{false};
     Slot* slots = nullptr;
 
-    void share(int t) {
+    // claims one part of thread v's share in run g; -1 when the share is exhausted
+    int claim(int v, uint32_t g, int nparts) {
+        const int lo = (int)((long long)nparts * v / nthreads), hi = (int)((long long)nparts * (v + 1) / nthreads);
+        std::atomic<uint64_t>& w = slots[v].claim;
+        uint64_t cur = w.load(std::memory_order_relaxed);
+        for (;;) {
+            const int idx = (uint32_t)(cur >> 32) == g ? (int)(uint32_t)cur : lo;
+            if (idx >= hi) return -1;
+            if (w.compare_exchange_weak(cur, ((uint64_t)g << 32) | (uint32_t)(idx + 1), std::memory_order_relaxed)) return idx;
+        }
+    }
+    void share(int t, uint32_t g) {
+        const int nparts = parts;
+        void (*const f)(void*, int) = fn;
+        void* const a = arg;
         for (int k = 0; k < nthreads; ++k) {  // own share first, then the others' leftovers
-            Slot& s = slots[(t + k) % nthreads];
-            for (;;) {
-                if (s.next.load(std::memory_order_relaxed) >= s.end) break;  // cheap look before touching the line for real
-                const int p = s.next.fetch_add(1, std::memory_order_relaxed);
-                if (p >= s.end) break;
-                fn(arg, p);
-            }
+            const int v = t + k < nthreads ? t + k : t + k - nthreads;
+            for (int p; (p = claim(v, g, nparts)) >= 0;) f(a, p);
         }
     }
     void loop(int t) {
         uint64_t seen = 0;
         for (;;) {
-            // the calls of one labelling run arrive ~100 us apart: spin for a while before going to sleep
+            // the calls of one labelling run arrive ~40 us apart: spin for a while before going to sleep
             int spins = 0;
             uint64_t g;
             while ((g = generation.load(std::memory_order_acquire)) == seen && !stop.load(std::memory_order_relaxed)) {
@@ -91,8 +108,8 @@ struct Workers::Impl {
             }
             if (stop.load()) return;
             seen = g;
-            share(t);
-            slots[t].done.store(g, std::memory_order_release);
+            share(t, (uint32_t)g);
+            remaining.fetch_sub(1, std::memory_order_release);
         }
     }
 };
@@ -221,23 +238,19 @@ void Workers::run(int parts, void (*fn)(void*, int), void* arg) {
         return;
     }
     Impl& s = *impl_;
-    // every worker has reported the previous generation (run() waited for it), so nobody reads these while they change
+    // every worker has finished the previous run (run() waited for it), so nobody reads the job while it changes
     s.parts = parts;
     s.fn = fn;
     s.arg = arg;
-    for (int t = 0; t < nthreads_; ++t) {
-        s.slots[t].end = (int)((long long)parts * (t + 1) / nthreads_);
-        s.slots[t].next.store((int)((long long)parts * t / nthreads_), std::memory_order_relaxed);
-    }
+    s.remaining.store(nthreads_ - 1, std::memory_order_relaxed);
     uint64_t g;
     {
         std::lock_guard<std::mutex> lk(s.m);  // pairs with the sleepers' predicate check
         g = s.generation.fetch_add(1, std::memory_order_release) + 1;
     }
     s.cv.notify_all();
-    s.share(0);
-    for (int t = 1; t < nthreads_; ++t)
-        while (s.slots[t].done.load(std::memory_order_acquire) != g) cpu_relax();
+    s.share(0, (uint32_t)g);
+    while (s.remaining.load(std::memory_order_acquire) != 0) cpu_relax();
 }
 
 int default_host_threads() {

@@ -1,0 +1,61 @@
+"""CPU: the host worker pool and the map packers under ThreadSanitizer (sanitizers run on the CPU build only).  The pool's
+fork-join is lock-free on its hot path - a generation counter the idle workers poll, generation-tagged claim words, one
+join counter - so its memory ordering is checked here, together with the packers that run on it (bands writing
+neighbouring strips and table entries, the stream's atomic reservation)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "3d_gaussian_splatting_project_amd", "csrc")
+
+DRIVER = r'''
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "host_pack.hpp"
+int main() {
+    const long long bad = gsx::workers_stress(6, 4000, 150);
+    std::printf("stress wrong parts: %lld\n", bad);
+    if (bad) return 2;
+    const int w = 330, h = 75;
+    const gsx::MapLayout L = gsx::map_layout(w, h, true, true);
+    const gsx::CompactLayout C = gsx::compact_layout(L);
+    std::vector<int32_t> seg((size_t)w * h);
+    for (size_t i = 0; i < seg.size(); ++i) seg[i] = (int)((i / 7) % 150) - 1;
+    std::vector<uint8_t> scratch(L.fine_bytes + 4096), rec(C.capacity + 4096), plain(L.map_bytes + 4096);
+    gsx::Workers pool(5);
+    for (int cut = 0; cut < 3; ++cut) {
+        gsx::set_host_parts_target(cut == 1 ? 256 : 1);
+        gsx::set_host_band_group(cut == 2 ? 3 : 1);
+        for (int r = 0; r < 60; ++r) {
+            size_t blocks = 0;
+            if (gsx::host_pack_map_compact(&pool, seg.data(), 0, L, 151, scratch.data(), rec.data(), &blocks)) return 3;
+            if (gsx::host_pack_map(&pool, seg.data(), 0, L, 151, plain.data())) return 4;
+        }
+    }
+    std::vector<int32_t> lab(100000);
+    std::vector<uint8_t> bins(100000, 7);
+    gsx::host_widen_labels(&pool, lab.data(), bins.data(), bins.size());
+    std::printf("done\n");
+    return 0;
+}
+'''
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_pool_and_packers_under_thread_sanitizer(tmp_path):
+    src = tmp_path / "main.cpp"
+    src.write_text(DRIVER)
+    exe = tmp_path / "tsan_pack"
+    build = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-I", CSRC, str(src), os.path.join(CSRC, "host_pack.cpp"),
+                            "-o", str(exe), "-lpthread"], capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in (build.stderr or "").lower():
+        pytest.skip("ThreadSanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66"))
+    assert run.returncode == 0 and "done" in run.stdout, (run.returncode, run.stdout[-500:], run.stderr[-3000:])
+    assert "WARNING: ThreadSanitizer" not in run.stderr
