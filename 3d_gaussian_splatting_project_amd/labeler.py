@@ -14,6 +14,13 @@ import numpy as np
 from . import _lib
 from ._lib import Camera, check
 
+try:  # CPython binding of the per-view hand-over (csrc/gsxfast.c); without it the ctypes path below does the same
+    from . import _gsxfast as _fast
+except ImportError:
+    _fast = None
+if os.environ.get("GSX_NO_FAST_BINDING"):
+    _fast = None
+
 
 def load_cameras(camera_file):
     """cameras.json -> list of dicts (reference: deep_learning_segmentation.py:17-22)."""
@@ -31,6 +38,7 @@ class Context:
         h = C.c_void_p()
         check(self._lib.gsx_create(int(device), C.byref(h)))
         self.h = h
+        self._vote_view_addr = C.cast(self._lib.gsx_vote_view, C.c_void_p).value   # for the CPython fast path
         self.device = int(device)
         self._keep_alive = []   # device maps handed to vote_view until the ctx stream has consumed them
 
@@ -106,6 +114,13 @@ class Context:
         packed_u8: a uint8 map already holds label+1 (0 = label -1), the library's own compact form.
         Host maps are range-checked here (ValueError); device maps when the labels are fetched."""
         cam = camera if isinstance(camera, Camera) else Camera.from_dict(camera)
+        if _fast is not None and type(seg_map) is np.ndarray and self.h is not None:
+            # the usual case in C (csrc/gsxfast.c): a contiguous 2-D int32 / int64 / uint8 array; anything else is declined
+            iw, ih = (-1, -1) if image_size is None else (int(image_size[0]), int(image_size[1]))
+            rc = _fast.vote_view(self._vote_view_addr, self.h.value, C.addressof(cam), seg_map, packed_u8, iw, ih)
+            if rc != _fast.DECLINED:
+                check(rc, self.h)
+                return
         if type(seg_map) is not np.ndarray and hasattr(seg_map, "data_ptr"):  # torch tensor on the device
             t = seg_map.contiguous()
             h, w = t.shape

@@ -624,6 +624,38 @@ def test_device_map_range_error_is_reported_with_the_labels(ctx, gsx):
     assert set(ctx.vote_finalize().tolist()) <= {3, -1}
 
 
+def test_python_binding_fast_path_and_ctypes_path_agree(gsx):
+    """Context.vote_view hands contiguous int32 / int64 / uint8 arrays over through the CPython module (csrc/gsxfast.c) and
+    everything else through ctypes; both must stage the same views, report the same errors, and the module must be in use."""
+    lab = gsx.labeler
+    assert lab._fast is not None, "the CPython binding (_gsxfast.so) was not built or not importable"
+    n = 30_000
+    pos, cams, segs = scene.make_scene(n, 4, 320, 180, config_id=14, convention="w2c")
+    sizes = [(320, 180)] * 4
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    fast = lab._fast
+    try:
+        for use_fast in (True, False):
+            lab._fast = fast if use_fast else None
+            with gsx.Context(0) as c:
+                for conv in (lambda s: s, lambda s: s.astype(np.int64), lambda s: np.asfortranarray(s), lambda s: s.astype(np.int16),
+                             lambda s: np.ascontiguousarray(s[::-1])[::-1]):
+                    assert np.array_equal(run_gpu(c, pos, cams, [conv(s) for s in segs], sizes).vote_finalize(), want)
+                ro = segs[0].copy()
+                ro.flags.writeable = False
+                c.vote_begin(150, 0, 1)
+                c.vote_view(cams[0], ro, sizes[0])                       # read-only arrays are fine
+                bad = segs[0].copy()
+                bad[5, 7] = 150
+                c.vote_begin(150, 0, 2)
+                with pytest.raises(ValueError, match="outside"):
+                    c.vote_view(cams[0], bad, sizes[0])
+                c.vote_view(cams[0], segs[0], sizes[0])                  # the refused map staged nothing
+                assert c.vote_num_views() == 1
+    finally:
+        lab._fast = fast
+
+
 def test_host_maps_cross_pcie_in_compact_form(gsx):
     """gsx_vote_view: the workers write the compact form (coarse level + the mixed cells' blocks) into the pinned ring, one DMA
     per group moves the records, seg_expand_kernel rebuilds the pool form.  The pool must hold exactly the bytes of the numpy
