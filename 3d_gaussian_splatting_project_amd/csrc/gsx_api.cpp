@@ -193,12 +193,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;
-    else if (k == "host_band_group") gsx::set_host_band_group((int)value);
     else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);
-    else if (k == "host_parts") {  // process-wide; between runs only (a group of pending records is expanded with one cut)
-        if (c->pend_count) return gsx::fail(c, GSX_E_STATE, "set_option host_parts: maps are pending");
-        gsx::set_host_parts_target((int)value);
-    }
     else if (k == "ablate") c->opt_ablate = (int)value;
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
@@ -347,14 +342,10 @@ int gsx_debug_widen_labels(int32_t threads, const uint8_t* bins, int64_t n, int3
         return GSX_E_HIP;  /* the pool could not be created (thread / memory exhaustion) */
     }
 }
-void gsx_debug_host_cut(int32_t parts_target, int32_t band_group) {
-    gsx::set_host_parts_target(parts_target);
-    gsx::set_host_band_group(band_group);
-}
 int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t threads, uint8_t* out,
-                                int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* seg_strips, int32_t* bad) {
+                                int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad) {
     try {
-        return gsx::debug_host_pack_compact(seg, seg_dtype, w, h, n_classes, threads, out, out_cap, bytes, table_bytes, stream_off, seg_strips, bad);
+        return gsx::debug_host_pack_compact(seg, seg_dtype, w, h, n_classes, threads, out, out_cap, bytes, table_bytes, stream_off, bad);
     } catch (...) {
         return GSX_E_HIP;
     }

@@ -272,7 +272,7 @@ void vote_release_host(Ctx* c);  // pinned buffers, events, worker pool (gsx_des
 int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes, int tiled, int coarse, int threads,
                     uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off, int32_t* bad);
 int debug_host_pack_compact(const void* seg, int seg_dtype, int w, int h, int n_classes, int threads, uint8_t* out, int64_t out_cap,
-                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* seg_strips, int32_t* bad);
+                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad);
 int vote_rewind(Ctx* c);
 int vote_finalize(Ctx* c, int32_t* labels_out);
 int vote_flush(Ctx* c);

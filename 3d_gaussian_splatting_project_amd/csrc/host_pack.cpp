@@ -417,8 +417,6 @@ struct PackJob {
     unsigned bins;
     uint8_t* dst;     // full-resolution level (strips)
     uint8_t* coarse;  // coarse level (plain form: dst + L.coarse_off)
-    int nseg = 1, seg_strips = 0;  // a unit = one band x one segment of seg_strips strips (map_segments)
-    int units = 0, group = 1;      // a part of the fork-join = `group` consecutive units
     // compact form only
     uint32_t* table = nullptr;
     uint8_t* stream = nullptr;
@@ -439,31 +437,32 @@ static void pack_band_tiled(PackJob* j, int part) {
     const unsigned bins = j->bins;
     uint8_t* const dst = j->dst;
     const T* seg = static_cast<const T*>(j->seg);
-    const int band = part / j->nseg, sgm = part % j->nseg;
-    const int y0 = band * 8, y1 = y0 + 8 < L.h ? y0 + 8 : L.h;
+    const int band = part;  // 8 pixel rows = two rows of cells
+    constexpr int c0 = 0, c1 = 2;
+    const int r0 = band * 8, r1 = r0 + 8;                               // pixel rows of this band ...
+    const int y0 = r0 < L.h ? r0 : L.h, y1 = r1 < L.h ? r1 : L.h;       // ... that exist
     const int strips = (L.w + 15) / 16, full = L.w / 16;
-    const int s0 = sgm * j->seg_strips, s1 = s0 + j->seg_strips < strips ? s0 + j->seg_strips : strips;  // this part's strips
-    const int nfull = (full < s1 ? full : s1) - s0;  // whole strips among them
     unsigned bad = 0;
     for (int y = y0; y < y1; ++y) {
         const T* row = seg + (size_t)y * L.w;
         uint8_t* o = dst + (size_t)y * 16;  // row y of strip 0
-        if (nfull > 0) bad |= rows16<T, ADD>(row + (size_t)s0 * 16, 16, nfull, bins, o + (size_t)s0 * L.strip_bytes, (size_t)L.strip_bytes);
-        if (full < strips && s1 == strips) {  // ragged last strip: columns past the map hold bin 0
+        if (full) bad |= rows16<T, ADD>(row, 16, full, bins, o, (size_t)L.strip_bytes);
+        if (full < strips) {  // ragged last strip: columns past the map hold bin 0
             uint8_t* e = o + (size_t)full * L.strip_bytes;
             std::memset(e, 0, 16);
             bad |= narrow_n<T, ADD>(row + (size_t)full * 16, L.w - full * 16, bins, e);
         }
     }
-    for (int s = s0; s < s1; ++s) {
+    for (int s = 0; s < strips; ++s) {
         const int x0 = s * 16;
         const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
-        uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)y0 * 16;
-        if (y1 - y0 < 8) std::memset(line + (y1 - y0) * 16, 0, (size_t)(8 - (y1 - y0)) * 16);  // rows past the map: defined bytes
+        uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)band * 128;
+        const int z0 = y1 > r0 ? y1 : r0;  // this band's rows past the map: defined bytes
+        if (z0 < r1) std::memset(line + (size_t)(z0 - band * 8) * 16, 0, (size_t)(r1 - z0) * 16);
         if (L.cstrip_bytes) {
             // coarse cells of this strip: 4 per cell row; a cell holds the bin its 16 pixels share, else 255
             // (cells that stick out of the map are "mixed": the vote then reads the exact pixel)
-            for (int cyl = 0; cyl < 2; ++cyl) {
+            for (int cyl = c0; cyl < c1; ++cyl) {
                 const int cy = band * 2 + cyl;
                 if (cy >= L.ch) break;
                 uint32_t word = 0xffffffffu;
@@ -491,22 +490,20 @@ static void pack_band_tiled(PackJob* j, int part) {
     }
     if (bad) j->bad.fetch_or(1u, std::memory_order_relaxed);
     if (j->stream) {
-        // compact form: the band's mixed cells (coarse byte 255) go to the stream as 16-byte blocks, cell row by cell row
-        // and inside a row by cell column; uniform cells are their coarse byte.  The strips' lines of this band were
+        // compact form: the mixed cells (coarse byte 255) of this band's two cell rows go to the stream as 16-byte blocks, cell
+        // row by cell row and inside a row by cell column; uniform cells are their coarse byte.  The strips' lines were
         // written a moment ago: they are in this core's cache.  Cost ~ the number of mixed cells: a row of 16 cells is one
-        // compare + movemask.
+        // compare + movemask.  table[2 * band + c] = where cell row c's blocks start.
         constexpr int kMaxCs = 1024;  // coarse strips of a 65535-pixel row
         uint16_t masks[2][kMaxCs];
-        const int cs0 = s0 >> 2, cs1 = (s1 + 3) >> 2;  // this part's coarse strips (a segment is a whole number of them)
-        uint32_t n = 0;
-        int rows_here = 0;
-        for (int cyl = 0; cyl < 2; ++cyl) {
+        const int ncs = (L.cw + 15) >> 4;
+        uint32_t n[2] = {0, 0};
+        for (int cyl = c0; cyl < c1; ++cyl) {
             const int cy = band * 2 + cyl;
             if (cy >= L.ch) break;
-            rows_here = cyl + 1;
-            if ((L.cw & 15) && s1 == strips)  // the cells past the map's last cell column: defined bytes (the level goes into the pool as it is)
+            if (L.cw & 15)  // the cells past the map's last cell column: defined bytes (the level goes into the pool as it is)
                 std::memset(j->coarse + (size_t)(L.cw >> 4) * L.cstrip_bytes + (size_t)cy * 16 + (L.cw & 15), 0, (size_t)(16 - (L.cw & 15)));
-            for (int cs = cs0; cs < cs1; ++cs) {
+            for (int cs = 0; cs < ncs; ++cs) {
                 const uint8_t* co = j->coarse + (size_t)cs * L.cstrip_bytes + (size_t)cy * 16;
                 unsigned m;
 #if defined(__x86_64__)
@@ -516,15 +513,18 @@ static void pack_band_tiled(PackJob* j, int part) {
                 for (int k = 0; k < 16; ++k) m |= (unsigned)(co[k] == 255) << k;
 #endif
                 masks[cyl][cs] = (uint16_t)m;  // padding cells are 0, never 255
-                n += (unsigned)__builtin_popcount(m);
+                n[cyl] += (unsigned)__builtin_popcount(m);
             }
         }
-        const uint32_t first = n ? j->blocks.fetch_add(n, std::memory_order_relaxed) : 0u;
-        j->table[part] = first;
-        uint8_t* out = j->stream + (size_t)first * 16;
-        for (int cyl = 0; cyl < rows_here && n; ++cyl) {
-            const uint8_t* rows = dst + (size_t)(y0 + cyl * 4) * 16;  // row 4*cyl of the band in strip 0
-            for (int cs = cs0; cs < cs1; ++cs) {
+        const uint32_t total = n[0] + n[1];
+        uint32_t first = total ? j->blocks.fetch_add(total, std::memory_order_relaxed) : 0u;
+        for (int cyl = c0; cyl < c1; ++cyl) {
+            j->table[2 * band + cyl] = first;
+            uint8_t* out = j->stream + (size_t)first * 16;
+            first += n[cyl];
+            if (!n[cyl]) continue;
+            const uint8_t* rows = dst + (size_t)(band * 8 + cyl * 4) * 16;  // row 4*cyl of the band in strip 0
+            for (int cs = 0; cs < ncs; ++cs) {
                 for (unsigned m = masks[cyl][cs]; m; m &= m - 1) {
                     const int cx = cs * 16 + __builtin_ctz(m);
                     const uint8_t* q = rows + (size_t)(cx >> 2) * L.strip_bytes + (cx & 3) * 4;  // rows 16 bytes apart
@@ -554,29 +554,15 @@ static void pack_band_rows(PackJob* j, int band) {  // row-major u8 map ("seg_ti
 template <typename T, unsigned ADD>
 static void pack_part(void* arg, int part) {
     PackJob* j = static_cast<PackJob*>(arg);
-    const int lo = part * j->group, hi = lo + j->group < j->units ? lo + j->group : j->units;
-    for (int u = lo; u < hi; ++u) {
-        if (j->L.strip_bytes) pack_band_tiled<T, ADD>(j, u);
-        else pack_band_rows<T, ADD>(j, u);
-    }
+    if (j->L.strip_bytes) pack_band_tiled<T, ADD>(j, part);
+    else pack_band_rows<T, ADD>(j, part);
 }
 
-// A band of 8 rows is cut into segments of whole coarse strips (64 pixel columns) so that a 1080p map is ~270 parts, not
-// 135: with 16 threads the last parts of a call decide how long it takes, and a part should be a small share of a thread's work.
-static std::atomic<int> g_parts_target{1};  // measured: cutting bands into column segments (256 -> 270 parts per 1080p map) makes the hand-over 12 % SLOWER
-static std::atomic<int> g_band_group{1};
-void set_host_band_group(int bands) { g_band_group.store(bands < 1 ? 1 : bands > 64 ? 64 : bands); }
-void set_host_parts_target(int parts) { g_parts_target.store(parts < 1 ? 1 : parts); }
-void map_segments(const MapLayout& L, int* nseg, int* seg_strips) {
-    const int strips = (L.w + 15) / 16, bands = (L.h + 7) / 8;
-    int n = L.strip_bytes ? (g_parts_target.load(std::memory_order_relaxed) + bands - 1) / bands : 1;
-    if (n > 4) n = 4;
-    int per = ((strips + n - 1) / n + 3) / 4 * 4;  // whole coarse strips
-    if (per < 4) per = 4;
-    *seg_strips = per;
-    *nseg = (strips + per - 1) / per;
-}
-
+// A map is cut into bands of 8 pixel rows, one part of the fork-join each, dealt in contiguous shares: every thread streams
+// through one piece of the map.  Measured and removed again in round 2, all slower on the GPU box: bands cut into column
+// segments (270 parts per 1080p map: +12 %), several bands per part (+0..12 %), and the bands that do not divide evenly
+// (135 = 16 x 8 + 7) handed out as single cell rows so that no thread idles at the end (+6.5 %: a part that does not continue a
+// thread's stream starts cold, 8 KB of prefetch distance behind).
 int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst) {
     PackJob j;
     j.seg = seg;
@@ -588,10 +574,7 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
                              : seg_dtype == 1 ? pack_part<int64_t, 1u>
                              : seg_dtype == 2 ? pack_part<uint8_t, 0u>
                                               : pack_part<uint8_t, 1u>;
-    map_segments(L, &j.nseg, &j.seg_strips);
-    const int bands = ((L.h + 7) / 8 * j.nseg + g_band_group.load() - 1) / g_band_group.load();  // parts
-    j.units = (L.h + 7) / 8 * j.nseg;
-    j.group = g_band_group.load();
+    const int bands = (L.h + 7) / 8;
     // the coarse level's padding (cell rows / columns past the map) is never read; zero it so that a packed map is a
     // function of the map alone (the all-gather of protocol v4 ships these bytes)
     if (L.cstrip_bytes) std::memset(dst + L.coarse_off, 0, L.map_bytes - L.coarse_off);
@@ -605,10 +588,8 @@ int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout
 
 CompactLayout compact_layout(const MapLayout& L) {
     CompactLayout C;
-    map_segments(L, &C.nseg, &C.seg_strips);
     C.bands = (L.h + 7) / 8;
-    C.parts = C.bands * C.nseg;
-    C.table_bytes = ((size_t)C.parts * 4 + 255) / 256 * 256;
+    C.table_bytes = ((size_t)C.bands * 8 + 255) / 256 * 256;  // one entry per cell row = two per band
     C.coarse_bytes = (L.map_bytes - L.coarse_off + 255) / 256 * 256;
     C.stream_off = C.table_bytes + C.coarse_bytes;
     C.capacity = C.stream_off + (size_t)L.cw * (size_t)L.ch * 16;
@@ -626,24 +607,19 @@ int host_pack_map_compact(Workers* pool, const void* seg, int seg_dtype, const M
     j.coarse = rec + C.table_bytes;
     j.table = reinterpret_cast<uint32_t*>(rec);
     j.stream = rec + C.stream_off;
-    j.nseg = C.nseg;
-    j.seg_strips = C.seg_strips;
     void (*fn)(void*, int) = seg_dtype == 0   ? pack_part<int32_t, 1u>
                              : seg_dtype == 1 ? pack_part<int64_t, 1u>
                              : seg_dtype == 2 ? pack_part<uint8_t, 0u>
                                               : pack_part<uint8_t, 1u>;
-    std::memset(rec + (size_t)C.parts * 4, 0, C.table_bytes - (size_t)C.parts * 4);
+    std::memset(rec + (size_t)C.bands * 8, 0, C.table_bytes - (size_t)C.bands * 8);
     // cell rows past the map (a coarse strip has room for a multiple of 8): defined bytes, like the cell columns past the
     // map that the bands clear - the level goes into the pool as it is
     const size_t row_room = (size_t)L.cstrip_bytes / 16;
     for (int cs = 0; cs * 16 < L.cw && row_room > (size_t)L.ch; ++cs)
         std::memset(j.coarse + (size_t)cs * L.cstrip_bytes + (size_t)L.ch * 16, 0, (row_room - (size_t)L.ch) * 16);
-    j.units = C.parts;
-    j.group = g_band_group.load();
-    const int nparts = (C.parts + j.group - 1) / j.group;
-    if (pool) pool->run(nparts, fn, &j);
+    if (pool) pool->run(C.bands, fn, &j);
     else
-        for (int b = 0; b < nparts; ++b) fn(&j, b);
+        for (int b = 0; b < C.bands; ++b) fn(&j, b);
     *blocks = j.blocks.load();
     return j.bad.load() ? 1 : 0;
 }

@@ -49,27 +49,22 @@ int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HO
 // `pool` may be nullptr (single thread).
 int host_pack_map(Workers* pool, const void* seg, int seg_dtype, const MapLayout& L, int bins, uint8_t* dst);
 // The COMPACT transfer form of a two-level map (what crosses PCIe for a host map; tiled + coarse layouts only):
-//   [0, table_bytes)                     uint32 first_block[parts]: where the part's mixed cells start in the stream (a part =
-//                                        one band of 8 pixel rows x one segment of seg_strips strips, part = band * nseg + segment)
+//   [0, table_bytes)                     uint32 first_block[2 * bands]: where the blocks of each cell row start in the
+//                                        stream (a band of 8 pixel rows holds two cell rows: entry 2 * band + row)
 //   [table_bytes, +coarse_bytes)         the coarse level exactly as it sits in the pool (padding zeroed)
 //   [stream_off, stream_off + 16*blocks) one 16-byte block (4 rows x 4 pixels, u8 bins) per MIXED 4x4 cell (coarse byte 255:
-//                                        the cell's pixels differ, or it sticks out of the map), part by part in the
-//                                        order the parts' workers reserved room (an atomic counter: the order differs from
-//                                        run to run, the table says where), inside a part cell row by cell row (a band has
-//                                        two), inside a cell row by cell column
+//                                        the cell's pixels differ, or it sticks out of the map); inside a cell row by cell
+//                                        column, the cell rows in the order their workers reserved room (an atomic counter:
+//                                        the order differs from run to run, the table says where)
 // Uniform cells travel as their coarse byte alone; the GPU rebuilds the full-resolution level (seg_expand_kernel).
 struct CompactLayout {
     int bands = 0;             // bands of 8 pixel rows
-    int nseg = 1, seg_strips = 0, parts = 0;  // a band is cut into nseg segments of seg_strips strips: parts = bands * nseg
     size_t table_bytes = 0;    // 256-B aligned pieces
     size_t coarse_bytes = 0;
     size_t stream_off = 0;
     size_t capacity = 0;       // stream_off + room for every cell being mixed
 };
 CompactLayout compact_layout(const MapLayout& L);
-void map_segments(const MapLayout& L, int* nseg, int* seg_strips);  // how the packers cut a band of a tiled map into parts
-void set_host_band_group(int bands);     // process-wide: consecutive bands one part of the fork-join takes (default 1)
-void set_host_parts_target(int parts);
 void set_host_prefetch(int bytes);       // process-wide: how far ahead the narrowing loops prefetch the map (default 8 KB)  // process-wide: parts per map the cut aims for (default 256; 1 = one part per band)
 // Packs `seg` into the compact form at rec (capacity bytes), using `scratch` (L.fine_bytes bytes of ordinary memory: the
 // narrowed strips live there for the duration of the call).  *blocks = 16-byte blocks in the stream.

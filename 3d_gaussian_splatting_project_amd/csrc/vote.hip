@@ -393,8 +393,8 @@ __global__ __launch_bounds__(kBlock) void seg_pack_fused_kernel(PackArgs a) {
 // Host maps arrive in the COMPACT form of host_pack.hpp (coarse level + one 16-byte block per mixed 4x4 cell: the PCIe
 // link, not the host pass, is what a run's hand-over waits for, and a segmentation map is mostly uniform cells).  This
 // kernel, queued behind the DMA of a group of maps on a GPU that has nothing else to do while maps are handed over,
-// rebuilds the pool form: one workgroup = one part (a band of 8 pixel rows x a segment of strips) of one map; a thread takes cells in the stream's
-// order (cell row of the band, cell column), a ballot scan ranks the mixed ones, and every cell is written
+// rebuilds the pool form: one workgroup = one band of 8 pixel rows (two cell rows) of one map; a thread takes the cells of a
+// cell row in the stream's order (by cell column), a ballot scan ranks the mixed ones, and every cell is written
 // as four 4-byte rows - its block, or its coarse byte four times over.  The coarse level is copied as it is; every
 // byte of the map's pool stride is written (cells and rows past the map, alignment gaps: 0), so a pool map stays a pure
 // function of the map, which exchange protocol v4 ships.
@@ -402,61 +402,63 @@ __global__ __launch_bounds__(kBlock) void seg_pack_fused_kernel(PackArgs a) {
 struct ExpandArgs {
     const uint8_t* rec[kCompactBatch];  // compact records in the device staging buffer
     uint8_t* map[kCompactBatch];        // their places in the pool
-    int w, h, strip_bytes, cstrip_bytes, cw, ch, strips, nseg, seg_strips;
+    int w, h, strip_bytes, cstrip_bytes, cw, ch, strips;
     unsigned table_bytes, stream_off, coarse_off, fine_bytes, map_bytes, stride;
-    unsigned max_block;  // last block a record of this geometry can hold, counted from the band's first
+    unsigned max_block;  // last block a cell row of this geometry can hold, counted from its first
 };
 
 __global__ __launch_bounds__(kBlock) void seg_expand_kernel(ExpandArgs a) {
     __shared__ unsigned wave_total[kBlock / 64];
     const uint8_t* __restrict__ rec = a.rec[blockIdx.y];
     uint8_t* __restrict__ map = a.map[blockIdx.y];
-    const int part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int band = part / a.nseg, s0 = (part - band * a.nseg) * a.seg_strips;  // a part = a band x a segment of strips (host_pack.hpp)
-    const int s1 = min(a.strips, s0 + a.seg_strips);
+    const int band = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint8_t* __restrict__ coarse = rec + a.table_bytes;
-    const uint4* __restrict__ stream = reinterpret_cast<const uint4*>(rec + a.stream_off) + reinterpret_cast<const uint32_t*>(rec)[part];
-    const int per = (s1 - s0) * 4, ncells = per * 2;  // cells per cell row (padded to whole strips); a band has two cell rows
-    unsigned running = 0;  // mixed cells of this band before the current round
-    for (int i0 = 0; i0 < ncells; i0 += kBlock) {
-        const int i = i0 + tid;
-        const bool valid = i < ncells;
-        const int cyl = i >= per ? 1 : 0, cx = s0 * 4 + i - cyl * per;  // the stream's order: cell row by cell row, then by column
-        const int s = cx >> 2, cc = cx & 3, cy = band * 2 + cyl;
-        const bool cell = valid && cy < a.ch && cx < a.cw;
-        const unsigned cb = cell ? coarse[(size_t)(cx >> 4) * a.cstrip_bytes + (cx & 15) + ((size_t)cy << 4)] : 0u;
-        const bool mixed = cell && cb == 255u;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(mixed);
-        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-        __syncthreads();  // the previous round's totals have been read
-        if (lane == 0) wave_total[wv] = (unsigned)__popcll(m);
-        __syncthreads();
-        unsigned before = running;
+    const uint32_t* __restrict__ table = reinterpret_cast<const uint32_t*>(rec);
+    const uint4* __restrict__ stream = reinterpret_cast<const uint4*>(rec + a.stream_off);
+    const int per = a.strips * 4;  // cells per cell row (padded to whole strips)
+    for (int cyl = 0; cyl < 2; ++cyl) {  // the band's two cell rows: each has its own run of blocks in the stream
+        const int cy = band * 2 + cyl;
+        const unsigned first = table[2 * band + cyl];
+        unsigned running = 0;  // mixed cells of this cell row before the current round
+        for (int i0 = 0; i0 < per; i0 += kBlock) {
+            const int cx = i0 + tid;
+            const bool valid = cx < per;
+            const int s = cx >> 2, cc = cx & 3;
+            const bool cell = valid && cy < a.ch && cx < a.cw;
+            const unsigned cb = cell ? coarse[(size_t)(cx >> 4) * a.cstrip_bytes + (cx & 15) + ((size_t)cy << 4)] : 0u;
+            const bool mixed = cell && cb == 255u;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(mixed);
+            const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            __syncthreads();  // the previous round's totals have been read
+            if (lane == 0) wave_total[wv] = (unsigned)__popcll(m);
+            __syncthreads();
+            unsigned before = running;
 #pragma unroll
-        for (int k = 0; k < kBlock / 64; ++k) {
-            before += k < wv ? wave_total[k] : 0u;
-            running += wave_total[k];
-        }
-        if (valid) {
-            uint32_t r0, r1, r2, r3;
-            if (mixed) {
-                const uint4 b = stream[min(before + below, a.max_block)];  // (a record is the library's own: the clamp never acts)
-                r0 = b.x, r1 = b.y, r2 = b.z, r3 = b.w;
-            } else {
-                r0 = r1 = r2 = r3 = cb * 0x01010101u;  // a uniform cell; 0 for the cells and rows past the map
+            for (int k = 0; k < kBlock / 64; ++k) {
+                before += k < wv ? wave_total[k] : 0u;
+                running += wave_total[k];
             }
-            uint8_t* o = map + (size_t)s * a.strip_bytes + ((size_t)(band * 8 + cyl * 4) << 4) + cc * 4;
-            *reinterpret_cast<uint32_t*>(o) = r0;
-            *reinterpret_cast<uint32_t*>(o + 16) = r1;
-            *reinterpret_cast<uint32_t*>(o + 32) = r2;
-            *reinterpret_cast<uint32_t*>(o + 48) = r3;
+            if (valid) {
+                uint32_t r0, r1, r2, r3;
+                if (mixed) {
+                    const uint4 b = stream[first + min(before + below, a.max_block)];  // (a record is the library's own: the clamp never acts)
+                    r0 = b.x, r1 = b.y, r2 = b.z, r3 = b.w;
+                } else {
+                    r0 = r1 = r2 = r3 = cb * 0x01010101u;  // a uniform cell; 0 for the cells and rows past the map
+                }
+                uint8_t* o = map + (size_t)s * a.strip_bytes + ((size_t)(band * 8 + cyl * 4) << 4) + cc * 4;
+                *reinterpret_cast<uint32_t*>(o) = r0;
+                *reinterpret_cast<uint32_t*>(o + 16) = r1;
+                *reinterpret_cast<uint32_t*>(o + 32) = r2;
+                *reinterpret_cast<uint32_t*>(o + 48) = r3;
+            }
         }
     }
     // the coarse level, verbatim (16-byte pieces dealt over the bands), and the alignment gaps
     const unsigned cbytes = a.map_bytes - a.coarse_off;  // a multiple of 128
-    for (unsigned j = (unsigned)part * kBlock + tid; j < cbytes / 16; j += gridDim.x * kBlock)
+    for (unsigned j = (unsigned)band * kBlock + tid; j < cbytes / 16; j += gridDim.x * kBlock)
         reinterpret_cast<uint4*>(map + a.coarse_off)[j] = reinterpret_cast<const uint4*>(coarse)[j];
-    if (part == 0) {
+    if (band == 0) {
         for (unsigned j = a.fine_bytes + tid; j < a.coarse_off; j += kBlock) map[j] = 0;
         for (unsigned j = a.map_bytes + tid; j < a.stride; j += kBlock) map[j] = 0;
     }
@@ -1437,13 +1439,12 @@ int vote_flush_pending(Ctx* c) {
         }
         a.w = L.w, a.h = L.h, a.strip_bytes = L.strip_bytes, a.cstrip_bytes = L.cstrip_bytes, a.cw = L.cw, a.ch = L.ch;
         a.strips = (L.w + 15) / 16;
-        a.nseg = CL.nseg, a.seg_strips = CL.seg_strips;
         a.table_bytes = (unsigned)CL.table_bytes, a.stream_off = (unsigned)CL.stream_off, a.coarse_off = (unsigned)L.coarse_off;
         a.fine_bytes = (unsigned)L.fine_bytes, a.map_bytes = (unsigned)L.map_bytes, a.stride = (unsigned)((L.map_bytes + 255) / 256 * 256);
-        a.max_block = (unsigned)(2 * L.cw - 1);  // a band holds two cell rows
+        a.max_block = (unsigned)(L.cw - 1);
         if (!c->opt_ablate) {  // (an ablation leaves no valid record to expand)
             ProfScope ps(c, "seg_expand");
-            hipLaunchKernelGGL(seg_expand_kernel, dim3((unsigned)CL.parts, (unsigned)c->pend_count), dim3(kBlock), 0, c->stream, a);
+            hipLaunchKernelGGL(seg_expand_kernel, dim3((unsigned)CL.bands, (unsigned)c->pend_count), dim3(kBlock), 0, c->stream, a);
             GSX_HIP(c, hipGetLastError());
         }
         c->pend_count = 0;
@@ -1520,14 +1521,13 @@ int debug_host_pack(const void* seg, int seg_dtype, int w, int h, int n_classes,
 
 // test hook, host only: the compact transfer form of one map (host_pack.hpp), as gsx_vote_view writes it into the pinned ring
 int debug_host_pack_compact(const void* seg, int seg_dtype, int w, int h, int n_classes, int threads, uint8_t* out, int64_t out_cap,
-                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* seg_strips, int32_t* bad) {
+                            int64_t* bytes, int64_t* table_bytes, int64_t* stream_off, int32_t* bad) {
     if (!seg || w < 1 || h < 1 || w > 65535 || h > 65535 || n_classes < 1 || n_classes > 254 || seg_dtype < 0 || seg_dtype > 3 || !bytes)
         return fail(nullptr, GSX_E_INVALID, "debug_host_pack_compact: bad arguments");
     const MapLayout L = map_layout(w, h, true, true);
     const CompactLayout CL = compact_layout(L);
     if (table_bytes) *table_bytes = (int64_t)CL.table_bytes;
     if (stream_off) *stream_off = (int64_t)CL.stream_off;
-    if (seg_strips) *seg_strips = CL.seg_strips;
     *bytes = (int64_t)CL.capacity;
     if (!out) return GSX_OK;
     if (out_cap < (int64_t)CL.capacity) return fail(nullptr, GSX_E_INVALID, "debug_host_pack_compact: output buffer too small");

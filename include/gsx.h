@@ -371,19 +371,15 @@ int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad);
 /* test hook, host only: the COMPACT transfer form in which gsx_vote_view sends a two-level map over PCIe (option
- * "host_compact", default 1): uint32 first_block[parts] | the coarse level as in the pool | one 16-byte block (4 rows x 4
- * pixels) per mixed 4x4 cell.  A part = a band of 8 pixel rows x a segment of *seg_strips strips of 16 pixel columns (part =
- * band * segments + segment); the parts' blocks follow each other in the order their workers reserved room (the table says
- * where), inside a part by cell row, then cell column.  out == NULL: *bytes = worst-case size; otherwise bytes in use. */
+ * "host_compact", default 1): uint32 first_block[2 * bands of 8 pixel rows] | the coarse level as in the pool | one 16-byte
+ * block (4 rows x 4 pixels) per mixed 4x4 cell.  A band holds two rows of cells; entry 2 * band + row says where that cell
+ * row's blocks start, inside a cell row they follow the cell columns; the cell rows follow each other in the order their
+ * workers reserved room.  out == NULL: *bytes = worst-case size; otherwise bytes in use.
+ * Option "host_prefetch" (default 8192): bytes the narrowing loops prefetch ahead of themselves (NTA hint; a negative value
+ * selects T0). */
 int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t threads,
                                 uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off,
-                                int32_t* seg_strips, int32_t* bad);
-/* test / tuning hook, process-wide, between runs only: how the host packers cut a map into the parts of their fork-join.
- * parts_target (default 1): a band of 8 pixel rows is cut into column segments until a map has about that many parts
- * (options "host_parts"); band_group (default 1): consecutive bands one part takes ("host_band_group").  Both measured
- * slower than one band per part on the GPU box; results never change.  Option "host_prefetch"
- * (default 8192): bytes the narrowing loops prefetch ahead of themselves (NTA hint; a negative value selects T0). */
-void gsx_debug_host_cut(int32_t parts_target, int32_t band_group);
+                                int32_t* bad);
 /* test hook, host only: `runs` fork-joins of pseudo-random size (1..max_parts parts) on ONE worker pool of `threads` threads;
  * returns how many parts did not run exactly once (0 = the pool is sound), -1 if the pool could not be created */
 int64_t gsx_debug_workers_stress(int32_t threads, int32_t runs, int32_t max_parts);

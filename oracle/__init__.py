@@ -436,7 +436,7 @@ def pack_map_numpy(seg, n_classes):
     return out, coarse_off
 
 
-def expand_compact_numpy(rec, w, h, table_bytes, stream_off, seg_strips):
+def expand_compact_numpy(rec, w, h, table_bytes, stream_off):
     """The pool form of a map from its COMPACT transfer form (csrc/host_pack.hpp; what seg_expand_kernel does on the GPU),
     restated in numpy: -> bytes equal to pack_map_numpy(seg)[0]."""
     rec = np.asarray(rec, np.uint8)
@@ -450,17 +450,15 @@ def expand_compact_numpy(rec, w, h, table_bytes, stream_off, seg_strips):
     out = np.zeros(coarse_off + cbytes, np.uint8)
     coarse = rec[table_bytes:table_bytes + cbytes]
     out[coarse_off:] = coarse
-    nseg = (strips + seg_strips - 1) // seg_strips                 # a part = a band x a segment of seg_strips strips
-    table = rec[:4 * bands * nseg].view(np.uint32)
+    table = rec[:8 * bands].view(np.uint32)                        # one entry per cell row: 2 * band + row of the band
     stream = rec[stream_off:]
-    for part in range(bands * nseg):
-        b, sg = divmod(part, nseg)
-        k = int(table[part])
-        for cyl in range(2):                                       # the stream's order: cell row, then cell column
+    for b in range(bands):
+        for cyl in range(2):
             cy = 2 * b + cyl
             if cy >= ch:
                 continue                                           # rows past the map stay 0
-            for cx in range(4 * sg * seg_strips, min(cw, 4 * (sg + 1) * seg_strips)):
+            k = int(table[2 * b + cyl])
+            for cx in range(cw):                                   # inside a cell row: by cell column
                 s, c = cx >> 2, cx & 3
                 base = s * strip_bytes + (8 * b + 4 * cyl) * 16 + 4 * c
                 cb = coarse[(cx >> 4) * cstrip_bytes + (cx & 15) + cy * 16]

@@ -121,42 +121,36 @@ def test_labels_cross_pcie_as_bytes_widened_on_the_host():
     assert lib.gsx_debug_widen_labels(1, None, 4, None) == labeler._lib.GSX_E_INVALID
 
 
-@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (4, 4), (16, 8), (17, 9), (61, 35), (64, 64), (65, 33), (130, 71), (330, 40), (1280, 16)])
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (4, 4), (16, 8), (17, 9), (61, 35), (64, 64), (65, 33), (130, 71), (330, 40), (64, 81), (48, 1080)])
 def test_compact_transfer_form_expands_to_the_pool_form(w, h):
     """What gsx_vote_view sends over PCIe (coarse level + the mixed cells' blocks) rebuilds, cell by cell, exactly the pool form:
     the numpy restatement of the GPU's expansion applied to the host packer's record == the numpy restatement of the layout.
-    Under every cut of the map into fork-join parts: one band per part (the default), column segments, grouped bands."""
+    Thread counts that divide the bands evenly and ones that do not."""
     import ctypes as C
     import oracle
     lib = labeler._lib.lib()
     rng = np.random.default_rng(w * 1000 + h)
 
     def record(seg, threads):
-        nb, tb, so, ss, bad = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
+        nb, tb, so, bad = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
         assert lib.gsx_debug_host_pack_compact(seg.ctypes.data, 0, w, h, 150, threads, None, 0, C.byref(nb), C.byref(tb), C.byref(so),
-                                               C.byref(ss), C.byref(bad)) == 0
+                                               C.byref(bad)) == 0
         rec = np.full(nb.value, 0xAB, np.uint8)
         assert lib.gsx_debug_host_pack_compact(seg.ctypes.data, 0, w, h, 150, threads, rec.ctypes.data, rec.size, C.byref(nb), C.byref(tb),
-                                               C.byref(so), C.byref(ss), C.byref(bad)) == 0
+                                               C.byref(so), C.byref(bad)) == 0
         assert nb.value <= rec.size
-        return rec[:nb.value], tb.value, so.value, ss.value, bad.value
+        return rec[:nb.value], tb.value, so.value, bad.value
 
-    try:
-        for trial, cut in enumerate(((1, 1), (256, 1), (256, 3))):
-            lib.gsx_debug_host_cut(*cut)
-            blocks = rng.integers(-1, 150, size=((h + 7) // 8, (w + 7) // 8), dtype=np.int32)
-            seg = np.repeat(np.repeat(blocks, 8, 0), 8, 1)[:h, :w].copy()
-            noise = rng.random((h, w)) < (0.0, 0.03, 0.5)[trial]
-            seg[noise] = rng.integers(-1, 150, size=int(noise.sum()))
-            ref, _ = oracle.pack_map_numpy(seg, 150)
-            for threads in (1, 4):
-                rec, tb, so, ss, bad = record(seg, threads)
-                assert bad == 0
-                if w >= 330 and cut[0] > 1:
-                    assert ss < (w + 15) // 16                   # wide, low maps: a band is cut into several segments
-                assert np.array_equal(oracle.expand_compact_numpy(rec, w, h, tb, so, ss), ref), (w, h, cut, threads)
-                if trial == 0 and w % 8 == 0 and h % 8 == 0:
-                    assert rec.size == so                        # no mixed cell: the coarse level is all that travels
-    finally:
-        lib.gsx_debug_host_cut(1, 1)
-    assert record(np.full((h, w), 150, np.int32), 2)[4] == 1     # a label out of range is reported
+    for trial in range(3):
+        blocks = rng.integers(-1, 150, size=((h + 7) // 8, (w + 7) // 8), dtype=np.int32)
+        seg = np.repeat(np.repeat(blocks, 8, 0), 8, 1)[:h, :w].copy()
+        noise = rng.random((h, w)) < (0.0, 0.03, 0.5)[trial]
+        seg[noise] = rng.integers(-1, 150, size=int(noise.sum()))
+        ref, _ = oracle.pack_map_numpy(seg, 150)
+        for threads in (1, 2, 3, 4, 7):
+            rec, tb, so, bad = record(seg, threads)
+            assert bad == 0
+            assert np.array_equal(oracle.expand_compact_numpy(rec, w, h, tb, so), ref), (w, h, trial, threads)
+            if trial == 0 and w % 8 == 0 and h % 8 == 0:
+                assert rec.size == so                            # no mixed cell: the coarse level is all that travels
+    assert record(np.full((h, w), 150, np.int32), 2)[3] == 1     # a label out of range is reported

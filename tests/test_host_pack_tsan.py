@@ -27,15 +27,12 @@ int main() {
     std::vector<int32_t> seg((size_t)w * h);
     for (size_t i = 0; i < seg.size(); ++i) seg[i] = (int)((i / 7) % 150) - 1;
     std::vector<uint8_t> scratch(L.fine_bytes + 4096), rec(C.capacity + 4096), plain(L.map_bytes + 4096);
-    gsx::Workers pool(5);
-    for (int cut = 0; cut < 3; ++cut) {
-        gsx::set_host_parts_target(cut == 1 ? 256 : 1);
-        gsx::set_host_band_group(cut == 2 ? 3 : 1);
-        for (int r = 0; r < 60; ++r) {
-            size_t blocks = 0;
-            if (gsx::host_pack_map_compact(&pool, seg.data(), 0, L, 151, scratch.data(), rec.data(), &blocks)) return 3;
-            if (gsx::host_pack_map(&pool, seg.data(), 0, L, 151, plain.data())) return 4;
-        }
+    gsx::Workers pool(5), pool4(4), pool3(3);
+    for (int r = 0; r < 150; ++r) {   // 10 bands on 5, 4 and 3 threads: even and uneven shares, helpers at work
+        gsx::Workers& p = r % 3 == 0 ? pool : r % 3 == 1 ? pool4 : pool3;
+        size_t blocks = 0;
+        if (gsx::host_pack_map_compact(&p, seg.data(), 0, L, 151, scratch.data(), rec.data(), &blocks)) return 3;
+        if (gsx::host_pack_map(&p, seg.data(), 0, L, 151, plain.data())) return 4;
     }
     std::vector<int32_t> lab(100000);
     std::vector<uint8_t> bins(100000, 7);
