@@ -194,6 +194,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;
     else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);
+    else if (k == "host_prefetch_burst") gsx::set_host_prefetch_burst(value != 0);
     else if (k == "ablate") c->opt_ablate = (int)value;
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");

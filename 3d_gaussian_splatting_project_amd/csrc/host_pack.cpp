@@ -297,7 +297,9 @@ static unsigned rows16_scalar(const T* __restrict__ src, size_t pitch, int rows,
 // records) in the cache: 7.4 -> 6.85 ms.  (A negative value selects the T0 hint, for the A/B.)
 static int g_prefetch_bytes = 8192;
 static bool g_prefetch_t0 = false;
+static bool g_prefetch_burst = true;
 void set_host_prefetch(int bytes) { g_prefetch_t0 = bytes < 0; g_prefetch_bytes = bytes < 0 ? -bytes : bytes; }
+void set_host_prefetch_burst(bool on) { g_prefetch_burst = on; }
 static inline void prefetch_map(const void* p) {
 #if defined(__x86_64__)
     if (g_prefetch_t0) _mm_prefetch(static_cast<const char*>(p), _MM_HINT_T0);
@@ -443,6 +445,18 @@ static void pack_band_tiled(PackJob* j, int part) {
     const int y0 = r0 < L.h ? r0 : L.h, y1 = r1 < L.h ? r1 : L.h;       // ... that exist
     const int strips = (L.w + 15) / 16, full = L.w / 16;
     unsigned bad = 0;
+    {
+        // A band that does not continue this thread's stream (the first of its share, a band taken over from another thread)
+        // starts cold, a whole prefetch distance behind: ask for that distance at once (hand-over of 200 maps 6.87 -> 6.72 ms).
+        static thread_local const void* continues_at = nullptr;
+        const char* first = reinterpret_cast<const char*>(seg + (size_t)y0 * L.w);
+        const char* end = reinterpret_cast<const char*>(seg + (size_t)y1 * L.w);
+        if (first != continues_at && g_prefetch_burst) {
+            const char* stop = first + g_prefetch_bytes < end ? first + g_prefetch_bytes : end;
+            for (const char* q = first; q < stop; q += 64) prefetch_map(q);
+        }
+        continues_at = end;
+    }
     for (int y = y0; y < y1; ++y) {
         const T* row = seg + (size_t)y * L.w;
         uint8_t* o = dst + (size_t)y * 16;  // row y of strip 0

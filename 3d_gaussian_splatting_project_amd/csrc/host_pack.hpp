@@ -65,6 +65,7 @@ struct CompactLayout {
     size_t capacity = 0;       // stream_off + room for every cell being mixed
 };
 CompactLayout compact_layout(const MapLayout& L);
+void set_host_prefetch_burst(bool on);  // process-wide A/B switch: a band that starts a new stream asks for a whole prefetch distance at once (default on)
 void set_host_prefetch(int bytes);       // process-wide: how far ahead the narrowing loops prefetch the map (default 8 KB)  // process-wide: parts per map the cut aims for (default 256; 1 = one part per band)
 // Packs `seg` into the compact form at rec (capacity bytes), using `scratch` (L.fine_bytes bytes of ordinary memory: the
 // narrowed strips live there for the duration of the call).  *blocks = 16-byte blocks in the stream.

@@ -376,7 +376,7 @@ int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h
  * row's blocks start, inside a cell row they follow the cell columns; the cell rows follow each other in the order their
  * workers reserved room.  out == NULL: *bytes = worst-case size; otherwise bytes in use.
  * Option "host_prefetch" (default 8192): bytes the narrowing loops prefetch ahead of themselves (NTA hint; a negative value
- * selects T0). */
+ * selects T0); "host_prefetch_burst" (default 1): a band that starts a new stream asks for that distance at once. */
 int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t threads,
                                 uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* table_bytes, int64_t* stream_off,
                                 int32_t* bad);

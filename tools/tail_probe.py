@@ -38,8 +38,8 @@ a = np.array(rows)
 med = np.median(a, axis=0)
 print(f"hand-over {med[0]:.3f} ms  tail {med[1]:.3f} ms  span {med[2]:.3f} ms   (median of {RUNS}; min span {a[:,2].min():.3f}, tail min {a[:,1].min():.3f})")
 for name, val in (("labels_u8", 0), ("labels_u8", 1), ("host_compact", 0), ("ablate", 1), ("ablate", 2), ("ablate", 0), ("host_compact", 1),
-                  ("ablate", 1), ("ablate", 0), ("host_prefetch", 512), ("host_prefetch", -8192), ("host_prefetch", 8192), ("host_threads", 15), ("host_threads", 8),
-                  ("host_threads", 24), ("host_threads", 16)):
+                  ("ablate", 1), ("ablate", 0), ("host_prefetch", 512), ("host_prefetch", -8192), ("host_prefetch", 8192), ("host_prefetch_burst", 0),
+                  ("host_prefetch_burst", 1), ("host_threads", 15), ("host_threads", 8), ("host_threads", 24), ("host_threads", 16)):
     ctx.set_option(name, val)
     rows = []
     for r in range(RUNS + 3):
