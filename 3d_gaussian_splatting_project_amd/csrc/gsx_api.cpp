@@ -30,7 +30,7 @@ int fail(Ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
-ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
+ProfScope::ProfScope(Ctx* ctx, const char* name, hipStream_t on) : c(ctx), st(on ? on : ctx->stream) {
     if (!c->prof_on) return;
     int id = -1;
     for (size_t i = 0; i < c->prof_names.size(); ++i)
@@ -49,12 +49,12 @@ ProfScope::ProfScope(Ctx* ctx, const char* name) : c(ctx) {
     };
     if (!get(ev.start) || !get(ev.stop)) return;
     ev.name_id = id;
-    active = hipEventRecord(ev.start, c->stream) == hipSuccess;
+    active = hipEventRecord(ev.start, st) == hipSuccess;
 }
 
 ProfScope::~ProfScope() {
     if (!active) return;
-    (void)hipEventRecord(ev.stop, c->stream);
+    (void)hipEventRecord(ev.stop, st);
     c->prof_events.push_back(ev);
 }
 
@@ -193,6 +193,13 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;
+    else if (k == "early_vote") {
+        if (value < 0 || value > 2) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote must be 0, 1 or 2");
+        c->opt_early_vote = (int)value;
+    } else if (k == "early_vote_at") {
+        if (value < 1 || value > 1000) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote_at must be in [1,1000] (permille of the announced views)");
+        c->opt_early_at = (int)value;
+    }
     else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);
     else if (k == "host_prefetch_burst") gsx::set_host_prefetch_burst(value != 0);
     else if (k == "ablate") c->opt_ablate = (int)value;
@@ -453,6 +460,10 @@ int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx) {
 int64_t gsx_vote_link_bytes(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
     return (c && c->vote_begun) ? (int64_t)c->compact_bytes : 0;
+}
+int64_t gsx_vote_early_views(const gsx_ctx* ctx) {
+    const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
+    return c && c->early_state == 1 ? c->early_done : 0;
 }
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes) {

@@ -216,6 +216,19 @@ struct Ctx {
     DevBuf bcnt, bcodes;        // > 255 views on one GPU: per-batch u8 count planes [S][bins][n_pad], tie codes u16 [S][n_pad]
     DevBuf cand, codes;         // exchange v3: candidate masks u32[8][sn] of this slab; tie codes u16[n_pad]
     bool labels_valid = false;
+    // early vote (vote.hip: early_vote_stage): the views [0, early_done) are voted on a second stream while the host is
+    // still handing over the rest of the run; vote_finalize then only walks the views behind them
+    int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
+    int opt_early_at = 650;      // the stage starts when this many permille of the announced views are staged
+    int early_state = 0;         // 0: not started in this run, 1: started, -1: not available any more (rewind, pool moved)
+    int early_done = 0;          // views [0, early_done) are in ecnt / efv
+    hipStream_t stream2 = nullptr;
+    hipEvent_t early_maps_ev = nullptr, early_done_ev = nullptr, early_up_ev = nullptr;
+    DevBuf ecnt, efv;            // u8 [wave][bin][64]: counts / first-view codes of the early views
+    DevBuf erec;                 // u8 [wave][view][64]: bin + 1 voted by each Gaussian in each early view
+    DevBuf e_views, e_cull;      // descriptors and culling planes (pitch kEarlyPitch) of the run's views, filled stage by stage
+    void* h_early = nullptr;     // pinned staging of both
+    size_t h_early_cap = 0;
 
     // rasterizer (render.hip / blend.hip)
     int64_t rn = 0;                      // splats uploaded
@@ -253,7 +266,8 @@ struct ProfScope {
     Ctx* c;
     ProfEvent ev{};
     bool active = false;
-    ProfScope(Ctx* ctx, const char* name);
+    hipStream_t st = nullptr;
+    ProfScope(Ctx* ctx, const char* name, hipStream_t on = nullptr);  // on: the stream the kernel is launched on (default: ctx->stream)
     ~ProfScope();
 };
 

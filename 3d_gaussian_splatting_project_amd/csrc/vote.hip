@@ -687,6 +687,152 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 }
 
 // -------------------------------------------------------------------------------------------------
+// early vote, last stage (host side: early_vote_stage / vote_finalize).  While the host is still handing over the last
+// maps of a run, vote_fused_planes_kernel has already voted the views [0, E) on a second stream and left their
+// count plane cntA and first-view plane fvA (u8, wave-major [wave][bin][64]; code = 255 - view index, 0 = no vote).  This kernel is
+// what remains between the last map and the labels: the walk of vote_fused_labels_kernel over the views [E, V) only,
+// on a histogram that STARTS from cntA, and one pass over fvA.
+// The reference's winner (dls.py:303) is the bin with the largest total whose first vote is earliest.  A bin with
+// votes in [0, E) has its first vote there (fvA); among such bins the pass below maximises (total, fvA).  The reverse
+// walk's online rule maximises (total, earliest vote inside [E, V)) over the bins voted in [E, V); if that bin has
+// no vote in [0, E) it beats every other bin of its kind, and it wins only with a strictly larger total than the best
+// bin that was voted earlier.  If it has votes in [0, E) it is covered by the pass.
+// The planes are read as dwords by a transposed lane mapping (lane (g, t) = bins g, g+4, .. of Gaussians 4t .. 4t+3,
+// as the planes kernel stores them): 256 B per wave instruction instead of 64 single bytes.
+// -------------------------------------------------------------------------------------------------
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {  // v_pk_max_u16
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+
+template <int U, int DIV, int NQ>
+__global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                     const uint8_t* __restrict__ cntA,
+                                                                     const uint8_t* __restrict__ fvA,
+                                                                     const uint8_t* __restrict__ recA, int E,
+                                                                     int* __restrict__ labels, int ablate) {
+    extern __shared__ uint32_t lds[];
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const long long ic = valid ? i : 0;  // unconditional loads: all three in flight together with the planes' rows
+    const float xf = p.x[ic], yf = p.y[ic], zf = p.z[ic];
+    const double X = valid ? (double)xf : __builtin_nan("");  // lanes past the end never vote
+    const double Y = valid ? (double)yf : 0.0;
+    const double Z = valid ? (double)zf : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4;
+    // The wave's histogram block in LDS has the layout of its block in the planes, [bin][64 lanes] bytes (rows padded to
+    // a multiple of four bins): the counts of the views [0, E) arrive by a plain coalesced copy, and dword q * 64 + lane
+    // of either holds bin 4q + g of the Gaussians 4t .. 4t+3 (g = lane / 16, t = lane % 16) - what the pass over the
+    // first-view plane below needs side by side.  Bank behaviour of the walk is that of the row-per-thread layout: lanes
+    // voting one bin touch 16 consecutive dwords, lanes voting different bins collide now and then.
+    const int nq = (p.bins + 3) >> 2;
+    uint32_t* wl = lds + (threadIdx.x >> 6) * (nq * 64);  // nq * 256 bytes per wave
+    uint8_t* hw = reinterpret_cast<uint8_t*>(wl) + lane;   // hw[bin * 64]: this lane's counter of a bin
+    const long long wave_at = (ablate & 1) ? 0 : (i - lane) * p.bins;  // (ablate: timing experiments only, tools/early_probe.py)
+    const uint32_t* __restrict__ csrc = reinterpret_cast<const uint32_t*>(cntA + wave_at) + lane;
+    const uint32_t* __restrict__ fsrc = reinterpret_cast<const uint32_t*>(fvA + wave_at) + lane;
+    // unconditional load + select (a conditional load costs a branch per row; the rows past the last bin lie in the next
+    // wave's block or in the slack behind the planes, kEarlySlack)
+    auto plane_dword = [&](const uint32_t* __restrict__ src, int q) {
+        const uint32_t v = src[q * 64];
+        return 4 * q + g < p.bins ? v : 0u;
+    };
+    // A wave lives through a chain of memory round trips and only 16 waves fit a CU (the histograms): the fewer round
+    // trips, the shorter the kernel.  NQ > 0 (bins <= 4 NQ): the first-view rows are fetched right behind the counts and
+    // wait in NQ registers until the walk is over; NQ == 0: any bin count, planes in rounds of kRound rows.
+    constexpr int kRound = 13;
+    uint32_t fd[NQ > 0 ? NQ : 1];
+    if (NQ > 0) {
+        uint32_t w[NQ > 0 ? NQ : 1];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) w[q] = plane_dword(csrc, q);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) fd[q] = plane_dword(fsrc, q);  // right behind the counts: ONE round trip for both planes
+        __builtin_amdgcn_sched_barrier(0);                          // (keep all 2 NQ loads ahead of the first LDS write)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q < nq) wl[q * 64 + lane] = w[q];
+    } else {
+        for (int q0 = 0; q0 < nq; q0 += kRound) {
+            uint32_t w[kRound];
+#pragma unroll
+            for (int j = 0; j < kRound; ++j) w[j] = plane_dword(csrc, q0 + j);
+#pragma unroll
+            for (int j = 0; j < kRound; ++j)
+                if (q0 + j < nq) wl[(q0 + j) * 64 + lane] = w[j];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();  // the block is written and read by the lanes of ONE wave: LDS keeps a wave's order
+
+    int best = -1, bestc = 0;
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
+        int bin[U];
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (bin[u] >= 0) {
+                const int c = hw[bin[u] * 64] + 1;  // dls.py:295
+                hw[bin[u] * 64] = (uint8_t)c;
+                if (c >= bestc) {  // reverse order: the bin whose earliest vote in [E, V) comes first survives a tie
+                    bestc = c;
+                    best = bin[u];
+                }
+            }
+        }
+    };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
+    __builtin_amdgcn_wave_barrier();
+
+    // Largest 16-bit key total << 8 | first-view code over ALL bins, per Gaussian: two packed maxima per lane for its four
+    // Gaussians, v_perm_b32 pairs a dword of totals with a dword of codes.  A bin without a vote in [0, E) has code 0 and
+    // loses against an equal total with one: the order the tie rule asks for.
+    uint32_t m01 = 0u, m23 = 0u;
+    auto fold = [&](uint32_t f4, int q) {
+        const uint32_t hd = wl[q * 64 + lane];
+        m01 = pk_max_u16(m01, __builtin_amdgcn_perm(hd, f4, 0x05010400u));  // [T1 f1 T0 f0]
+        m23 = pk_max_u16(m23, __builtin_amdgcn_perm(hd, f4, 0x07030602u));  // [T3 f3 T2 f2]
+    };
+    if (NQ > 0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            if (q < nq) fold(fd[q], q);
+    } else {
+        for (int q0 = 0; q0 < nq; q0 += kRound) {
+            uint32_t f[kRound];
+#pragma unroll
+            for (int j = 0; j < kRound; ++j) f[j] = plane_dword(fsrc, q0 + j);
+#pragma unroll
+            for (int j = 0; j < kRound; ++j)
+                if (q0 + j < nq) fold(f[j], q0 + j);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {  // the four lanes (0..3, t) share their Gaussians
+        m01 = pk_max_u16(m01, (uint32_t)__shfl_xor((int)m01, o));
+        m23 = pk_max_u16(m23, (uint32_t)__shfl_xor((int)m23, o));
+    }
+    // Gaussian `lane` = 4 t' + k' is key k' of the lanes with t = t'
+    const uint32_t s01 = (uint32_t)__shfl((int)m01, lane >> 2), s23 = (uint32_t)__shfl((int)m23, lane >> 2);
+    const uint32_t pair = (lane & 2) ? s23 : s01;
+    const unsigned mine = (lane & 1) ? pair >> 16 : pair & 0xffffu;
+    if (valid) {
+        // code 0: no bin was voted in [0, E) and reached the total of the walk's winner -> the walk's winner (-1: no vote at
+        // all).  Otherwise the winner is the bin this Gaussian voted in view 255 - code: the early stage kept that record.
+        int win = best;
+        const unsigned code = mine & 0xffu;
+        if (code) win = (int)recA[(i - lane) * E + (255 - (int)code) * 64 + lane] - 1;
+        const long long o = p.perm ? (long long)p.perm[i] : i;
+        labels[o] = win - 1 + (win < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
 // exchange protocol v3, rank-local part 1: the same walk as the labels kernel (u8 counters, 16 waves/CU)
 // but the only output is this rank's COUNT plane, u8 [slab][bins][sn].  No first-view plane: ties are
 // resolved later, for the tied Gaussians only, by vote_tie_kernel.
@@ -863,7 +1009,8 @@ template <int U, typename PT, int DIV>
 __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    PT* __restrict__ cnt,
                                                                    PT* __restrict__ fv, long long sn,
-                                                                   int view_base, int fresh, int local_codes) {
+                                                                   int view_base, int fresh, int local_codes,
+                                                                   uint8_t* __restrict__ rec) {
     constexpr int FVMAX = sizeof(PT) == 1 ? 255 : 65535;
     extern __shared__ uint32_t lds[];
     uint32_t* row = lds + threadIdx.x * p.stride_dw;
@@ -883,6 +1030,13 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
         gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        if (rec) {  // early vote: the record of every vote, [wave][view][64 lanes] bytes (bin + 1, 0 = none) - the last stage
+                    // looks the winner's bin up by the view of its first vote
+            uint8_t* r = rec + (i - (threadIdx.x & 63)) * p.nviews + (threadIdx.x & 63);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (kFull || vb - 1 - u >= 0) r[(vb - 1 - u) * 64] = (uint8_t)(bin[u] + 1);
+        }
         unsigned old[U];  // one LDS round trip per chunk, repeats of a bin resolved in registers
 #pragma unroll
         for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (unsigned)h[bin[u]] : 0u;
@@ -1121,6 +1275,8 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->planes_zero = false;
     c->planes_stale = false;
     c->labels_valid = false;
+    c->early_state = 0;
+    c->early_done = 0;
     GSX_HIP(c, c->errflag.ensure(sizeof(int)));
     GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0x7f, sizeof(int), c->stream));  // kNoBadView
     c->vote_begun = true;
@@ -1132,6 +1288,10 @@ static int pool_reserve(Ctx* c, size_t need) {
     {
         const int rcf = vote_flush_pending(c);  // the pool is about to move: maps still waiting in the pinned ring go up first
         if (rcf) return rcf;
+    }
+    if (c->early_state == 1) {  // the early stage reads the pool that is about to be freed, and its planes refer to the old addresses
+        GSX_HIP(c, hipStreamSynchronize(c->stream2));
+        c->early_state = -1;
     }
     size_t cap = c->segpool.cap ? c->segpool.cap : ((size_t)64 << 20);
     while (cap < need) cap *= 2;
@@ -1210,7 +1370,9 @@ static Workers* host_workers(Ctx* c, const void* near = nullptr) {
 // Host map: the worker threads narrow it into the next slot of the pinned ring (u8 strips + coarse level, range
 // checked on the way: an out-of-range label fails THIS call), one asynchronous DMA moves the packed map into the
 // pool.  No kernel, no synchronisation; the call returns as soon as the caller's buffer has been read.
-int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int seg_w, int seg_h, int img_w, int img_h) {
+static int early_vote_stage(Ctx* c);
+
+static int vote_view_host(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int seg_w, int seg_h, int img_w, int img_h) {
     MapLayout L;
     int rc = view_prologue(c, "vote_view", cam, seg, 1, seg_dtype, seg_w, seg_h, img_w, img_h, L);
     if (rc) return rc;
@@ -1369,6 +1531,11 @@ int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int
     return GSX_OK;  // unreachable: both hand-over paths return above
 }
 
+int vote_view(Ctx* c, const gsx_camera* cam, const void* seg, int seg_dtype, int seg_w, int seg_h, int img_w, int img_h) {
+    const int rc = vote_view_host(c, cam, seg, seg_dtype, seg_w, seg_h, img_w, img_h);
+    return rc ? rc : early_vote_stage(c);  // enough of the run staged: its first views are voted while the rest is handed over
+}
+
 static void launch_pack(Ctx* c, const PackArgs& a, int jobs, int seg_dtype, bool vec, long long cells) {
     using K = void (*)(PackArgs);
     static const K table[4][2] = {{seg_pack_fused_kernel<int32_t, 1, false>, seg_pack_fused_kernel<int32_t, 1, true>},
@@ -1442,7 +1609,7 @@ int vote_flush_pending(Ctx* c) {
         a.table_bytes = (unsigned)CL.table_bytes, a.stream_off = (unsigned)CL.stream_off, a.coarse_off = (unsigned)L.coarse_off;
         a.fine_bytes = (unsigned)L.fine_bytes, a.map_bytes = (unsigned)L.map_bytes, a.stride = (unsigned)((L.map_bytes + 255) / 256 * 256);
         a.max_block = (unsigned)(L.cw - 1);
-        if (!c->opt_ablate) {  // (an ablation leaves no valid record to expand)
+        if (!(c->opt_ablate & 3)) {  // (an ablation of the hand-over leaves no valid record to expand)
             ProfScope ps(c, "seg_expand");
             hipLaunchKernelGGL(seg_expand_kernel, dim3((unsigned)CL.bands, (unsigned)c->pend_count), dim3(kBlock), 0, c->stream, a);
             GSX_HIP(c, hipGetLastError());
@@ -1501,6 +1668,20 @@ void vote_release_host(Ctx* c) {
     c->h_views_cap = 0;
     delete c->workers;
     c->workers = nullptr;
+    if (c->stream2) {
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamDestroy(c->stream2);
+        c->stream2 = nullptr;
+    }
+    for (hipEvent_t* e : {&c->early_maps_ev, &c->early_done_ev, &c->early_up_ev}) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+    }
+    if (c->h_early) (void)hipHostFree(c->h_early);
+    c->h_early = nullptr;
+    c->h_early_cap = 0;
+    for (DevBuf* b : {&c->ecnt, &c->efv, &c->erec, &c->e_views, &c->e_cull}) b->release();
+    c->early_state = -1;
 }
 
 // test hook, host only: the packed form of one map exactly as gsx_vote_view stages it
@@ -1703,6 +1884,7 @@ int vote_rewind(Ctx* c) {
     GSX_HIP(c, hipSetDevice(c->device));
     c->n_flushed = 0;
     c->labels_valid = false;
+    c->early_state = -1;  // a rewound run is voted in one piece (its views are all there)
     if (c->planes_valid) {
         c->planes_valid = false;
         c->planes_zero = false;
@@ -1720,6 +1902,141 @@ static int set_lds(Ctx* c, K kernel, size_t bytes) {
 }
 
 static constexpr int kUnroll = 8;
+
+// ---- early vote ---------------------------------------------------------------------------------------------------
+FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
+// A run is the hand-over of its maps (the host pass over them, ~37 us per 1080p map) followed by the vote over all of
+// them (~1.2 ms for 3 M Gaussians x 200 views) with the GPU idle during the first and the host during the second.
+// When `early_vote_at` permille of the announced views are staged, their vote starts on a second stream
+// (vote_fused_planes_kernel into ecnt / efv: counts and first-view codes per bin) while the host goes on packing; what
+// vote_finalize still has to do behind the last map is the walk over the remaining views plus one pass over the two
+// planes (vote_fused_final_kernel).  Same labels, bit for bit: the planes keep everything the tie rule needs.
+// Only where it pays and is simple: one rank holds all views of the run (<= 255), they arrive one by one through
+// gsx_vote_view, the branchless projection is on.  Anything else (rewind, flush, exchange protocols, a pool that had to
+// move) ignores the early planes and votes all views in one piece as before.
+static constexpr int kEarlyPitch = 256;                    // views per block of culling planes (>= kMaxBatch)
+static constexpr long long kEarlyMinGaussians = 1 << 18;   // below this the vote is too short to be worth a second stream
+static constexpr int kEarlyMinViews = 32;
+static constexpr size_t kEarlySlack = 64 * 260;           // the last stage reads whole groups of four rows, up to row 4 * kRegRows - 1, whatever the bin count
+static constexpr size_t kEarlyCullDoubles = (size_t)kCullStride * kCullPlanes * kEarlyPitch;
+
+static bool early_possible(const Ctx* c) {
+    return c->opt_early_vote && c->first_view == 0 && c->total_views <= kMaxBatch && !c->local_codes && c->slabs == 1 && !c->wide &&
+           c->n_flushed == 0 && !c->pool_base && c->opt_flat_project && c->n > 0 && c->bins <= 255 &&
+           (c->opt_early_vote == 2 || (c->n >= kEarlyMinGaussians && c->total_views >= kEarlyMinViews));
+}
+
+// Descriptors and culling planes of the views [lo, hi) -> e_views[lo..hi), culling block `block` of e_cull, on stream st.
+// dm: the projection variant these views allow.
+static int early_upload(Ctx* c, int lo, int hi, int block, hipStream_t st, int* dm) {
+    const size_t vbytes = sizeof(ViewDesc) * kEarlyPitch, cbytes = sizeof(double) * kEarlyCullDoubles;
+    if (!c->h_early) {
+        GSX_HIP(c, hipHostMalloc(&c->h_early, vbytes + 2 * cbytes, hipHostMallocDefault));
+        c->h_early_cap = vbytes + 2 * cbytes;
+    }
+    GSX_HIP(c, c->e_views.ensure(vbytes));
+    GSX_HIP(c, c->e_cull.ensure(2 * cbytes));
+    if (!c->early_up_ev) GSX_HIP(c, hipEventCreateWithFlags(&c->early_up_ev, hipEventDisableTiming));
+    else GSX_HIP(c, hipEventSynchronize(c->early_up_ev));  // the previous upload has left the staging buffer
+    ViewDesc* hv = static_cast<ViewDesc*>(c->h_early);
+    double* planes = reinterpret_cast<double*>(static_cast<char*>(c->h_early) + vbytes) + (size_t)block * kEarlyCullDoubles;
+    std::memset(planes, 0, cbytes);
+    const long long base = (long long)reinterpret_cast<uintptr_t>(c->segpool.p);
+    bool simple = true, coarse = true;
+    for (int i = lo; i < hi; ++i) {
+        ViewDesc& v = hv[i];
+        v = c->views[i];
+        v.seg_off += base;
+        simple = simple && v.unit_scale && v.seg_row_bytes;
+        coarse = coarse && v.coarse_row_bytes;
+        double pl[kCullStride * kCullPlanes];
+        cull_planes(v, pl);
+        for (int k = 0; k < kCullStride * kCullPlanes; ++k) planes[(size_t)k * kEarlyPitch + (i - lo)] = pl[k];
+    }
+    *dm = !simple ? kDivFlat : (coarse && c->opt_seg_coarse ? kDivFlatCoarse : kDivFlatSimple);
+    if (hi > lo) GSX_HIP(c, hipMemcpyAsync(c->e_views.as<ViewDesc>() + lo, hv + lo, sizeof(ViewDesc) * (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+    GSX_HIP(c, hipMemcpyAsync(c->e_cull.as<double>() + (size_t)block * kEarlyCullDoubles, planes, cbytes, hipMemcpyHostToDevice, st));
+    GSX_HIP(c, hipEventRecord(c->early_up_ev, st));
+    return GSX_OK;
+}
+
+static FusedParams early_params(Ctx* c, int lo, int hi, int block, int stride_bytes_per_bin) {
+    FusedParams p = fused_params(c, stride_bytes_per_bin);
+    p.views = c->e_views.as<ViewDesc>() + lo;
+    p.nviews = hi - lo;
+    p.cull = c->opt_wave_cull ? c->e_cull.as<double>() + (size_t)block * kEarlyCullDoubles : nullptr;
+    p.cull_pitch = kEarlyPitch;
+    return p;
+}
+
+static int early_vote_stage(Ctx* c) {
+    if (c->early_state != 0 || !early_possible(c)) return GSX_OK;
+    const int nv = (int)c->views.size();
+    const int at = std::max(1, (int)(((long long)c->total_views * c->opt_early_at + 999) / 1000));
+    if (nv != at || at >= c->total_views) return GSX_OK;
+    int rc = vote_flush_pending(c);  // the maps of these views are on their way on c->stream
+    if (rc) return rc;
+    if (!c->stream2) {
+        GSX_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
+        GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
+    }
+    const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
+    GSX_HIP(c, c->ecnt.ensure(plane + kEarlySlack));
+    GSX_HIP(c, c->efv.ensure(plane + kEarlySlack));
+    GSX_HIP(c, c->erec.ensure((size_t)c->n_pad * (size_t)at));
+    if (!c->d_cull_tally.p) {
+        GSX_HIP(c, c->d_cull_tally.ensure(sizeof(unsigned long long)));
+        GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof(unsigned long long), c->stream));
+    }
+    GSX_HIP(c, hipEventRecord(c->early_maps_ev, c->stream));
+    GSX_HIP(c, hipStreamWaitEvent(c->stream2, c->early_maps_ev, 0));
+    int dm = kDivFlat;
+    if ((rc = early_upload(c, 0, at, 0, c->stream2, &dm))) return rc;
+    FusedParams p = early_params(c, 0, at, 0, 2);
+    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+    auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
+             : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
+                                    : vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat>;
+    if ((rc = set_lds(c, k, lds))) return rc;
+    {
+        ProfScope ps(c, "vote_early_planes", c->stream2);
+        // fresh planes, one "slab" per wave (sn = 64: the wave-major layout the last stage streams), global view codes 255 - v
+        hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream2, p, p.views, c->ecnt.as<uint8_t>(), c->efv.as<uint8_t>(),
+                           64LL, 0, 1, 0, c->erec.as<uint8_t>());
+        GSX_HIP(c, hipGetLastError());
+    }
+    GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+    c->early_done = at;
+    c->early_state = 1;
+    return GSX_OK;
+}
+
+// vote_finalize behind an early stage: the views [early_done, nv) on top of the early planes -> c->labels
+static int early_vote_finish(Ctx* c) {
+    const int nv = (int)c->views.size();
+    int rc = vote_flush_pending(c);
+    if (rc) return rc;
+    int dm = kDivFlat;
+    if ((rc = early_upload(c, c->early_done, nv, 1, c->stream, &dm))) return rc;
+    GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    FusedParams p = early_params(c, c->early_done, nv, 1, 1);
+    const size_t lds = (size_t)(kBlock / 64) * ((c->bins + 3) / 4) * 256;  // per wave: [bin][64] bytes, rows padded to a multiple of four
+    constexpr int kRegRows = 38;  // bins <= 152 (the 150 ADE20K classes + unlabelled): the first-view rows wait in registers
+    const bool regs = c->bins <= 4 * kRegRows;
+    auto k = dm == kDivFlatCoarse ? (regs ? vote_fused_final_kernel<kUnroll, kDivFlatCoarse, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlatCoarse, 0>)
+             : dm == kDivFlatSimple ? (regs ? vote_fused_final_kernel<kUnroll, kDivFlatSimple, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlatSimple, 0>)
+                                    : (regs ? vote_fused_final_kernel<kUnroll, kDivFlat, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlat, 0>);
+    if ((rc = set_lds(c, k, lds))) return rc;
+    GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+    const int ablate = (c->opt_ablate >> 4) & 3;  // 16: every wave reads the planes of wave 0; 32: no views behind the early ones
+    if (ablate & 2) p.nviews = 0;
+    ProfScope ps(c, "vote_fused_final");
+    hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->ecnt.as<uint8_t>(), c->efv.as<uint8_t>(),
+                       c->erec.as<uint8_t>(), c->early_done, c->labels.as<int>(), ablate);
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
 
 // merge views [n_flushed, size) into the planes, kMaxBatch at a time
 int vote_flush(Ctx* c) {
@@ -1764,7 +2081,7 @@ int vote_flush(Ctx* c) {
                                            : vote_fused_planes_kernel<kUnroll, uint16_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint16_t>(),
-                               c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0);
+                               c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0, (uint8_t*)nullptr);
         } else {
             const int dm = div_mode(c);
             auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
@@ -1774,7 +2091,7 @@ int vote_flush(Ctx* c) {
                                            : vote_fused_planes_kernel<kUnroll, uint8_t, kDivExact>;
             if ((rc = set_lds(c, k, lds))) return rc;
             hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->cnt.as<uint8_t>(),
-                               c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0);
+                               c->fv.as<uint8_t>(), (long long)c->sn, view_base, fresh, c->local_codes ? 1 : 0, (uint8_t*)nullptr);
         }
         GSX_HIP(c, hipGetLastError());
         c->planes_zero = false;
@@ -2033,6 +2350,12 @@ int vote_finalize(Ctx* c, int32_t* labels_out) {
     GSX_HIP(c, hipSetDevice(c->device));
     const int nv = (int)c->views.size();
     const bool batched_ok = !c->local_codes && c->opt_batched_counts;
+    if (c->early_state == 1 && early_possible(c) && nv >= c->early_done && nv <= kMaxBatch) {
+        // the first views were voted while the rest was handed over: only the views behind them are left
+        int rc = early_vote_finish(c);
+        if (rc) return rc;
+        return labels_to_host(c, labels_out);
+    }
     if (c->n_flushed == 0 && (nv <= kMaxBatch || batched_ok)) {
         // nothing in the planes yet: labels come straight out of the fused kernel(s)
         int rc = labels_for_range(c, VoteRange{0, c->n}, false);

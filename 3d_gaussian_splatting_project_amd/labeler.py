@@ -295,6 +295,10 @@ class Context:
         """bytes of host maps sent over PCIe since vote_begin (compact records, or maps in pool form)"""
         return int(self._lib.gsx_vote_link_bytes(self.h))
 
+    def vote_early_views(self):
+        """views of this run that were voted on the second stream while the rest was handed over (0: one-piece vote)"""
+        return int(self._lib.gsx_vote_early_views(self.h))
+
     def vote_import(self, part_views, part_offsets, blobs, pool_all_ptr, pool_all_bytes):
         pv = np.ascontiguousarray(part_views, np.int32)
         po = np.ascontiguousarray(part_offsets, np.int64)

@@ -97,6 +97,12 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               mixed 4x4 cells only, and a kernel behind the DMA rebuilds the pool form (the link, not
  *                               the host pass, is what the hand-over of 200 1080p maps waits for); 0 = the pool form
  *                               itself crosses the link.  Same pool bytes, same labels
+ *   "early_vote"   (default 1)  a run whose views all arrive on this context through gsx_vote_view (first_view 0, at most
+ *                               255 announced, >= 32 of them, >= 2^18 Gaussians) votes its first views on a second stream
+ *                               while the host is still handing over the rest; gsx_vote_finalize then walks only the views
+ *                               behind them on top of the early counts.  Same labels, bit for bit.  0 = off, 2 = whatever
+ *                               the run's size (tests).  "early_vote_at" (default 650): the stage starts when this many
+ *                               permille of the announced views are staged
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
@@ -268,6 +274,9 @@ int64_t gsx_vote_pool_bytes(const gsx_ctx* ctx);
 /* statistics: bytes of HOST maps (gsx_vote_view) sent over PCIe since gsx_vote_begin - compact records (option
  * "host_compact") or maps in pool form */
 int64_t gsx_vote_link_bytes(const gsx_ctx* ctx);
+/* statistics: the run's first views that were voted on a second stream while the rest was still being handed over
+ * (option "early_vote"; 0: none, the run is voted in one piece by gsx_vote_finalize) */
+int64_t gsx_vote_early_views(const gsx_ctx* ctx);
 /* part r contributed part_views[r] views (blobs in part order) whose maps start at byte part_offsets[r] of
  * pool_all_dev (pool_all_bytes long; caller-owned, must stay alive and unchanged until the labels have been fetched).
  * Replaces the views staged so far; global view order = part order.  Blobs are validated against the pool size. */

@@ -197,6 +197,87 @@ def test_labels_match_reference_golden(ctx, case):
     assert np.array_equal(ctx.vote_finalize(), labels)
 
 
+def _kernel_launches(c, name):
+    return c.profile_get(name)[0] if name in c.profile_names() else 0
+
+
+@pytest.mark.parametrize("case", golden_assign_cases(), ids=lambda c: c[0])
+def test_early_vote_matches_reference_golden(gsx, case):
+    """The first views of a run voted on a second stream while the rest is handed over (option early_vote), the last stage
+    on top of their planes: the reference's labels for every split point, incl. the ties fixture."""
+    name, pos, cams, segs, sizes, labels = case
+    V = len(cams)
+    if V < 2:
+        pytest.skip("one view: nothing to split")
+    with gsx.Context(0) as c:
+        c.set_option("early_vote", 2)
+        c.profile(True)
+        finals = 0
+        for permille in sorted({1, 250, 500, 750, (1000 * (V - 1)) // V}):
+            c.set_option("early_vote_at", permille)
+            for wave_cull in (1, 0):
+                c.set_option("wave_cull", wave_cull)
+                got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+                assert np.array_equal(got, labels), (name, permille, wave_cull)
+                finals += max(1, -(-V * permille // 1000)) < V  # a stage that would take every view is not started
+                assert _kernel_launches(c, "vote_fused_final") == finals and _kernel_launches(c, "vote_early_planes") == finals
+            c.vote_rewind()  # a rewound run is voted in one piece
+            assert np.array_equal(c.vote_finalize(), labels)
+            assert _kernel_launches(c, "vote_fused_final") == finals
+
+
+def test_early_vote_on_a_large_scene(gsx):
+    """The automatic form (early_vote = 1: large scene, >= 32 views, all on this rank): random labels per pixel make most
+    Gaussians tied between several bins, so the first-view plane decides; ragged N; views that see nothing; a caller that
+    stops before the announced number of views; maps of two geometries (no coarse level for one)."""
+    n, V, W, H = 300_007, 40, 320, 180
+    pos, cams, segs = scene.make_scene(n, V, W, H, config_id=7, convention="w2c")
+    rng = np.random.default_rng(5)
+    segs = [rng.integers(-1, 150, size=(H, W)).astype(np.int32) for _ in range(V)]
+    segs[3] = np.full((H, W), -1, np.int32)
+    segs[V - 2] = np.full((H, W), 17, np.int32)
+    sizes = [(W, H)] * V
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    assert (want != -1).mean() > 0.5
+    with gsx.Context(0) as c:
+        c.profile(True)
+        got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+        assert np.array_equal(got, want)
+        assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 0
+        c.set_option("early_vote", 0)
+        assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want)
+        assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 1
+        c.set_option("early_vote", 1)
+        # 40 views announced, 33 handed over: the stage ran after 28, the last stage takes the 5 that came
+        want33 = oracle.assign_labels(pos, cams[:33], segs[:33], sizes[:33], threads=0)
+        c.upload_positions(pos)
+        c.vote_begin(150, 0, V)
+        for v in range(33):
+            c.vote_view(cams[v], segs[v], sizes[v])
+        assert np.array_equal(c.vote_finalize(), want33)
+        assert _kernel_launches(c, "vote_fused_final") == 2
+        # exactly the early views and nothing behind them
+        c.vote_begin(150, 0, V)
+        for v in range(28):
+            c.vote_view(cams[v], segs[v], sizes[v])
+        assert np.array_equal(c.vote_finalize(), oracle.assign_labels(pos, cams[:28], segs[:28], sizes[:28], threads=0))
+        assert _kernel_launches(c, "vote_fused_final") == 3
+        # a second geometry after the stage (the pool has room: no move), scaled lookups in the last stage
+        segs2 = list(segs)
+        sizes2 = list(sizes)
+        for v in range(30, V):
+            segs2[v] = rng.integers(-1, 150, size=(H // 2, W // 2)).astype(np.int64)
+        want2 = oracle.assign_labels(pos, cams, segs2, sizes2, threads=0)
+        assert np.array_equal(run_gpu(c, pos, cams, segs2, sizes2).vote_finalize(), want2)
+        # a larger geometry behind the stage: the pool moves, the early planes are dropped, one-piece vote
+        segs3 = list(segs)
+        for v in range(30, V):
+            segs3[v] = rng.integers(-1, 150, size=(H * 4, W * 4)).astype(np.int32)
+        want3 = oracle.assign_labels(pos, cams, segs3, sizes, threads=0)
+        with gsx.Context(0) as c2:
+            assert np.array_equal(run_gpu(c2, pos, cams, segs3, sizes).vote_finalize(), want3)
+
+
 def test_config2_sized_scene_vs_oracle(ctx):
     """BASELINE config 2 shape at reduced N: 16 views @720p, ragged N (not a multiple of 256)."""
     n = 150_001
@@ -870,6 +951,8 @@ def test_randomised_small_configurations(gsx):
             c.set_option("flat_project", int(rng.integers(0, 2)))
             c.set_option("wave_cull", int(rng.integers(0, 2)))
             c.set_option("seg_coarse", int(rng.integers(0, 2)))
+            c.set_option("early_vote", int(rng.choice([0, 2])))
+            c.set_option("early_vote_at", int(rng.integers(1, 1001)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
             for v in range(V):
