@@ -137,6 +137,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);  // an early vote stage may still read the buffers freed below
     gsx::prof_drain(c);
     for (auto ev : c->event_pool) (void)hipEventDestroy(ev);
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->errflag,

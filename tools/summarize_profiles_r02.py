@@ -56,9 +56,11 @@ for key, v in raw.items():
 json.dump(derived, open(os.path.join(dst, f"derived_{tag}.json"), "w"), indent=1)
 cached = {"_comment": f"PMC figures of profiles/r02/counters_by_kernel_{tag}.json (rocprofv3, separate --pmc passes; derivations in "
                       "tools/summarize_profiles_r02.py).  bench.py quotes them as CACHED profile figures next to its live timings."}
-v = derived.get("vote_fused_labels")
-if v:
-    cached["vote_fused_labels"] = {
+for name in ("vote_fused_labels", "vote_early_planes", "vote_fused_final"):
+    v = derived.get(name)
+    if not v:
+        continue
+    cached[name] = {
         "hbm_bytes_per_launch": v.get("hbm_bytes_per_launch"),
         "source": f"profiles/r02/derived_{tag}.json",
         "valu_f64": {"bound": "valu_f64", "achieved": v.get("valu_busy_simd_cycles"), "peak": v.get("simd_cycles_available"),
