@@ -219,7 +219,7 @@ struct Ctx {
     // early vote (vote.hip: early_vote_stage): the views [0, early_done) are voted on a second stream while the host is
     // still handing over the rest of the run; vote_finalize then only walks the views behind them
     int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
-    int opt_early_at = 650;      // the stage starts when this many permille of the announced views are staged
+    int opt_early_at = 700;      // the stage starts when this many permille of the announced views are staged
     int early_state = 0;         // 0: not started in this run, 1: started, -1: not available any more (rewind, pool moved)
     int early_done = 0;          // views [0, early_done) are in ecnt / efv
     hipStream_t stream2 = nullptr;

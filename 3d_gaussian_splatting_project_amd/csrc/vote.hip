@@ -494,6 +494,7 @@ struct FusedParams {
 // (nviews-1-v), so that the U views of a chunk are U adjacent bits.  Pairs that are not provably invisible take
 // the exact path as before: the result is unchanged, bit for bit.
 static constexpr int kCullPlanes = 5;
+static constexpr unsigned kTallySlots = 1024, kTallyStride = 16;  // u64 counters, one per 128-B line
 struct CullMasks {
     unsigned long long m[4];  // kMaxBatch <= 256 views
 };
@@ -543,8 +544,11 @@ __device__ __forceinline__ CullMasks wave_cull_masks(const double* __restrict__ 
             k.m[j] = __builtin_amdgcn_ballot_w64(out);
         }
     }
-    if (tally && lane == 0)  // statistics for gsx_vote_culled(): one atomic per wave
-        atomicAdd(tally, (unsigned long long)(__popcll(k.m[0]) + __popcll(k.m[1]) + __popcll(k.m[2]) + __popcll(k.m[3])));
+    if (tally && lane == 0) {  // statistics for gsx_vote_culled(): one atomic per wave, spread over kTallySlots cache lines -
+                               // 47 k atomics on ONE address keep an L2 channel busy for ~0.4 ms, longer than a short kernel runs
+        const unsigned slot = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) & (kTallySlots - 1);
+        atomicAdd(tally + slot * kTallyStride, (unsigned long long)(__popcll(k.m[0]) + __popcll(k.m[1]) + __popcll(k.m[2]) + __popcll(k.m[3])));
+    }
     return k;
 }
 
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams
     __builtin_amdgcn_wave_barrier();  // the block is written and read by the lanes of ONE wave: LDS keeps a wave's order
 
     int best = -1, bestc = 0;
-    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
+    const CullMasks cmask = wave_cull_masks((ablate & 32) ? nullptr : p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
@@ -798,7 +802,10 @@ __global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams
         m01 = pk_max_u16(m01, __builtin_amdgcn_perm(hd, f4, 0x05010400u));  // [T1 f1 T0 f0]
         m23 = pk_max_u16(m23, __builtin_amdgcn_perm(hd, f4, 0x07030602u));  // [T3 f3 T2 f2]
     };
-    if (NQ > 0) {
+    if (ablate & 4) {  // timing experiment: no pass over the first-view rows (they are still fetched)
+#pragma unroll
+        for (int q = 0; q < (NQ > 0 ? NQ : 1); ++q) m01 |= fd[q] & 1u;
+    } else if (NQ > 0) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
             if (q < nq) fold(fd[q], q);
@@ -826,8 +833,8 @@ __global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams
         // all).  Otherwise the winner is the bin this Gaussian voted in view 255 - code: the early stage kept that record.
         int win = best;
         const unsigned code = mine & 0xffu;
-        if (code) win = (int)recA[(i - lane) * E + (255 - (int)code) * 64 + lane] - 1;
-        const long long o = p.perm ? (long long)p.perm[i] : i;
+        if (code && !(ablate & 8)) win = (int)recA[(i - lane) * E + (255 - (int)code) * 64 + lane] - 1;
+        const long long o = (p.perm && !(ablate & 16)) ? (long long)p.perm[i] : i;
         labels[o] = win - 1 + (win < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
     }
 }
@@ -1771,13 +1778,23 @@ static void cull_planes(const ViewDesc& v, double out[kCullStride * kCullPlanes]
     }
 }
 
+static constexpr size_t kTallyBytes = sizeof(unsigned long long) * kTallySlots * kTallyStride;
+static int ensure_tally(Ctx* c) {
+    if (c->d_cull_tally.p) return GSX_OK;
+    GSX_HIP(c, c->d_cull_tally.ensure(kTallyBytes));
+    GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, kTallyBytes, c->stream));
+    return GSX_OK;
+}
+
 int vote_culled(Ctx* c, int64_t* out, bool reset) {
     unsigned long long h = 0;
     if (c->d_cull_tally.p) {
         GSX_HIP(c, hipSetDevice(c->device));
-        GSX_HIP(c, hipMemcpyAsync(&h, c->d_cull_tally.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
-        if (reset) GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof h, c->stream));
+        std::vector<unsigned long long> slots(kTallySlots * kTallyStride);
+        GSX_HIP(c, hipMemcpyAsync(slots.data(), c->d_cull_tally.p, kTallyBytes, hipMemcpyDeviceToHost, c->stream));
+        if (reset) GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, kTallyBytes, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
+        for (unsigned k = 0; k < kTallySlots; ++k) h += slots[(size_t)k * kTallyStride];
     }
     *out = (int64_t)h;
     return GSX_OK;
@@ -1836,9 +1853,9 @@ static int sync_views(Ctx* c) {
         GSX_HIP(c, hipMemcpyAsync(c->d_cull.p, planes, sizeof(double) * plane_doubles, hipMemcpyHostToDevice, c->stream));
         GSX_HIP(c, hipEventRecord(c->h_views_ev, c->stream));
         c->cull_pitch = pitch;
-        if (!c->d_cull_tally.p) {
-            GSX_HIP(c, c->d_cull_tally.ensure(sizeof(unsigned long long)));
-            GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof(unsigned long long), c->stream));
+        {
+            const int rct = ensure_tally(c);
+            if (rct) return rct;
         }
     }
     c->views_dirty = false;
@@ -1985,10 +2002,7 @@ static int early_vote_stage(Ctx* c) {
     GSX_HIP(c, c->ecnt.ensure(plane + kEarlySlack));
     GSX_HIP(c, c->efv.ensure(plane + kEarlySlack));
     GSX_HIP(c, c->erec.ensure((size_t)c->n_pad * (size_t)at));
-    if (!c->d_cull_tally.p) {
-        GSX_HIP(c, c->d_cull_tally.ensure(sizeof(unsigned long long)));
-        GSX_HIP(c, hipMemsetAsync(c->d_cull_tally.p, 0, sizeof(unsigned long long), c->stream));
-    }
+    if ((rc = ensure_tally(c))) return rc;
     GSX_HIP(c, hipEventRecord(c->early_maps_ev, c->stream));
     GSX_HIP(c, hipStreamWaitEvent(c->stream2, c->early_maps_ev, 0));
     int dm = kDivFlat;
@@ -2029,7 +2043,10 @@ static int early_vote_finish(Ctx* c) {
                                     : (regs ? vote_fused_final_kernel<kUnroll, kDivFlat, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlat, 0>);
     if ((rc = set_lds(c, k, lds))) return rc;
     GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
-    const int ablate = (c->opt_ablate >> 4) & 3;  // 16: every wave reads the planes of wave 0; 32: no views behind the early ones
+    // timing experiments (results invalid), option "ablate": 16 every wave reads the planes of wave 0; 32 no views behind the
+    // early ones; 64 no pass over the first-view rows; 128 no look-up in the vote record; 256 labels stored in Morton order;
+    // 512 no wave-level culling
+    const int ablate = (c->opt_ablate >> 4) & 63;
     if (ablate & 2) p.nviews = 0;
     ProfScope ps(c, "vote_fused_final");
     hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream, p, p.views, c->ecnt.as<uint8_t>(), c->efv.as<uint8_t>(),

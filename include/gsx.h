@@ -101,7 +101,7 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               255 announced, >= 32 of them, >= 2^18 Gaussians) votes its first views on a second stream
  *                               while the host is still handing over the rest; gsx_vote_finalize then walks only the views
  *                               behind them on top of the early counts.  Same labels, bit for bit.  0 = off, 2 = whatever
- *                               the run's size (tests).  "early_vote_at" (default 650): the stage starts when this many
+ *                               the run's size (tests).  "early_vote_at" (default 700): the stage starts when this many
  *                               permille of the announced views are staged
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link

@@ -55,15 +55,15 @@ def measure(tag):
 
 ctx.set_option("early_vote", 0)
 ref = measure("one piece      ")
-for at in (600, 700, 800):
+for at in (650,):
     ctx.set_option("early_vote", 1)
     ctx.set_option("early_vote_at", at)
     got = measure(f"early at {at:4d}")
     assert np.array_equal(got, ref), at
 ctx.set_option("early_vote_at", 700)
-for ab in (16, 32, 48, 0):     # timing only: planes of wave 0 for every wave / no views behind the early ones / both
+for ab in (16, 32, 64, 128, 256, 512, 32 + 64, 32 + 64 + 128 + 256 + 512, 0):     # timing only, see vote.hip early_vote_finish
     ctx.set_option("ablate", ab)
-    measure(f"at 700 ablate {ab:2d}")
+    measure(f"at 700 ablate {ab:4d}")
 # the last stage alone, back to back (the run's early planes are still there): what the kernel costs when nothing else runs
 ctx.profile(True)
 for r in range(10):
