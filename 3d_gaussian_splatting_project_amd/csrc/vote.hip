@@ -1994,7 +1994,10 @@ static int early_vote_stage(Ctx* c) {
     int rc = vote_flush_pending(c);  // the maps of these views are on their way on c->stream
     if (rc) return rc;
     if (!c->stream2) {
-        GSX_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        // lowest priority: the kernels that expand the maps still arriving (c->stream) get the CUs the stage's waves free first
+        int least = 0, greatest = 0;
+        GSX_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GSX_HIP(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
         GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
         GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
     }

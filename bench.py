@@ -503,6 +503,7 @@ def main():
                        "bound_to_gpu_numa_node": None if bound is None else f"{len(bound)} CPUs",
                        "setup_seconds": round(setup_s, 1),
                        "step_ms_median_min_max": [round(float(np.median(step_ms)), 3), round(min(step_ms), 3), round(max(step_ms), 3)],
+                       "step_ms": [round(x, 2) for x in step_ms],
                        "cpu_quota_throttling_in_timed_region": None if thr0 is None or thr1 is None else
                        {"scheduler_periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1],
                         "throttled_ms": round((thr1[2] - thr0[2]) / 1e3, 1)},
