@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
         for (int k = 0; k < nd; ++k) blend_one(acc, fxp, fyp, r0, r1, r2);
     }
     if (inside) image[(size_t)py * W + px] = make_float4(acc.r, acc.g, acc.b, acc.a);
-    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed + (blockIdx.x & (kConsumedSlots - 1)) * 16, (unsigned long long)staged);  // statistics, spread over
+                                                                                        // kConsumedSlots lines: same-address atomics serialise in one L2 channel
 }
 
 // ---- two pixels per thread ---------------------------------------------------------------------------------
@@ -230,7 +231,8 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     }
     if (in0) image[(size_t)py0 * W + px] = make_float4(acc.r.x, acc.g.x, acc.b.x, acc.a.x);
     if (in1) image[(size_t)py1 * W + px] = make_float4(acc.r.y, acc.g.y, acc.b.y, acc.a.y);
-    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed + (blockIdx.x & (kConsumedSlots - 1)) * 16, (unsigned long long)staged);  // statistics, spread over
+                                                                                        // kConsumedSlots lines: same-address atomics serialise in one L2 channel
 }
 
 // ---- four pixels per thread, one wave per tile ----------------------------------------------------------------
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     if (in[1]) image[(size_t)(row + 8) * W + px] = make_float4(accA.r.y, accA.g.y, accA.b.y, accA.a.y);
     if (in[2]) image[(size_t)(row + 4) * W + px] = make_float4(accB.r.x, accB.g.x, accB.b.x, accB.a.x);
     if (in[3]) image[(size_t)(row + 12) * W + px] = make_float4(accB.r.y, accB.g.y, accB.b.y, accB.a.y);
-    if (threadIdx.x == 0 && staged) atomicAdd(consumed, (unsigned long long)staged);
+    if (threadIdx.x == 0 && staged) atomicAdd(consumed + (blockIdx.x & (kConsumedSlots - 1)) * 16, (unsigned long long)staged);  // statistics, spread over
+                                                                                        // kConsumedSlots lines: same-address atomics serialise in one L2 channel
 }
 
 int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,

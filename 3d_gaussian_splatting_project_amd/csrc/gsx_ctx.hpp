@@ -111,6 +111,7 @@ static constexpr int kDmaBatch = 4;    // packed host maps per H2D copy (one hip
 static constexpr int kCompactBatch = 16;  // compact records per H2D copy and expansion launch (as many as fit into a group's part of the ring)
 static constexpr int kDmaGroups = 3;   // ring = kDmaGroups groups of kDmaBatch slots: one filling, one or two in flight
 static constexpr int kLabelChunks = 4;
+static constexpr int kConsumedSlots = 64;  // rasterizer statistics: the blend kernels' "pairs staged" counter, one slot per 128-B line
 static constexpr int kNoBadView = 0x7f7f7f7f;  // errflag value meaning "every device-side map was in range"
 
 struct ProfEvent {

@@ -773,11 +773,13 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     constexpr int kMaxPhases = 8;
     GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)ntiles));
     GSX_HIP(c, c->r_sat.ensure((size_t)ntiles));
-    GSX_HIP(c, c->r_small.ensure(256));
-    // [0]=min [1]=max [2]=dropped [3]=pad, then u64: [2]=pairs consumed, [3 + p]=pairs of phase p
+    constexpr size_t kSmallBytes = 256 + (size_t)kConsumedSlots * 128;
+    GSX_HIP(c, c->r_small.ensure(kSmallBytes));
+    // [0]=min [1]=max [2]=dropped [3]=pad, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
+    // counters 128 B apart (summed below)
     int* small = c->r_small.as<int>();
     unsigned long long* small64 = reinterpret_cast<unsigned long long*>(small);
-    unsigned long long* consumed_dev = small64 + 2;
+    unsigned long long* consumed_dev = small64 + 32;
     unsigned long long* pairs_dev = small64 + 3;
     c->r_P = 0;
     c->r_consumed = 0;
@@ -840,7 +842,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_vals0.ensure(4 * cap));
         GSX_HIP(c, c->r_vals1.ensure(4 * cap));
         GSX_HIP(c, hipMemsetAsync(c->r_sat.p, 0, (size_t)ntiles, c->stream));
-        static const int kInit[64] = {2147483647, -2147483647 - 1};  // depth min / max; counters 0 (static: outlives the copy)
+        static const int kInit[kSmallBytes / 4] = {2147483647, -2147483647 - 1};  // depth min / max; counters 0 (static: outlives the copy)
         GSX_HIP(c, hipMemcpyAsync(small, kInit, sizeof kInit, hipMemcpyHostToDevice, c->stream));
         {
             ProfScope ps(c, "render_pre");
@@ -907,7 +909,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             first_phase = 0;
         }
         // end of frame: the only host wait.  Did every phase fit the pair buffers?
-        unsigned long long stats[3 + kMaxPhases];
+        unsigned long long stats[kSmallBytes / 8];
         GSX_HIP(c, hipMemcpyAsync(stats, small, sizeof stats, hipMemcpyDeviceToHost, c->stream));
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         unsigned long long maxP = 0, sumP = 0;
@@ -924,7 +926,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             continue;
         }
         c->r_P = sumP;
-        c->r_consumed = stats[2];
+        c->r_consumed = 0;
+        for (int k = 0; k < kConsumedSlots; ++k) c->r_consumed += stats[32 + 16 * k];
         break;
     }
     if (rgba_out) {
