@@ -464,7 +464,7 @@ int64_t gsx_vote_link_bytes(const gsx_ctx* ctx) {
 }
 int64_t gsx_vote_early_views(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
-    return c && c->early_state == 1 ? c->early_done : 0;
+    return c && (c->early_state == 1 || c->early_batches > 0) ? c->early_done : 0;
 }
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes) {

@@ -222,7 +222,8 @@ struct Ctx {
     int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
     int opt_early_at = 700;      // the stage starts when this many permille of the announced views are staged
     int early_state = 0;         // 0: not started in this run, 1: started, -1: not available any more (rewind, pool moved)
-    int early_done = 0;          // views [0, early_done) are in ecnt / efv
+    int early_done = 0;          // views [0, early_done) are in ecnt / efv (or, > 255 announced views, in the first early_batches planes of bcnt)
+    int early_batches = 0;       // > 255 announced views: batches of labels_batched() whose count kernels already ran on stream2
     hipStream_t stream2 = nullptr;
     hipEvent_t early_maps_ev = nullptr, early_done_ev = nullptr, early_up_ev = nullptr;
     DevBuf ecnt, efv;            // u8 [wave][bin][64]: counts / first-view codes of the early views

@@ -1284,6 +1284,7 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->labels_valid = false;
     c->early_state = 0;
     c->early_done = 0;
+    c->early_batches = 0;
     GSX_HIP(c, c->errflag.ensure(sizeof(int)));
     GSX_HIP(c, hipMemsetAsync(c->errflag.p, 0x7f, sizeof(int), c->stream));  // kNoBadView
     c->vote_begun = true;
@@ -1296,9 +1297,10 @@ static int pool_reserve(Ctx* c, size_t need) {
         const int rcf = vote_flush_pending(c);  // the pool is about to move: maps still waiting in the pinned ring go up first
         if (rcf) return rcf;
     }
-    if (c->early_state == 1) {  // the early stage reads the pool that is about to be freed, and its planes refer to the old addresses
+    if (c->early_state == 1 || c->early_batches > 0) {  // the early stage reads the pool that is about to be freed
         GSX_HIP(c, hipStreamSynchronize(c->stream2));
         c->early_state = -1;
+        c->early_batches = 0;
     }
     size_t cap = c->segpool.cap ? c->segpool.cap : ((size_t)64 << 20);
     while (cap < need) cap *= 2;
@@ -1902,6 +1904,7 @@ int vote_rewind(Ctx* c) {
     c->n_flushed = 0;
     c->labels_valid = false;
     c->early_state = -1;  // a rewound run is voted in one piece (its views are all there)
+    c->early_batches = 0;
     if (c->planes_valid) {
         c->planes_valid = false;
         c->planes_zero = false;
@@ -1937,31 +1940,38 @@ static constexpr int kEarlyMinViews = 32;
 static constexpr size_t kEarlySlack = 64 * 260;           // the last stage reads whole groups of four rows, up to row 4 * kRegRows - 1, whatever the bin count
 static constexpr size_t kEarlyCullDoubles = (size_t)kCullStride * kCullPlanes * kEarlyPitch;
 
-static bool early_possible(const Ctx* c) {
-    return c->opt_early_vote && c->first_view == 0 && c->total_views <= kMaxBatch && !c->local_codes && c->slabs == 1 && !c->wide &&
-           c->n_flushed == 0 && !c->pool_base && c->opt_flat_project && c->n > 0 && c->bins <= 255 &&
+static bool early_common(const Ctx* c) {
+    return c->opt_early_vote && c->first_view == 0 && !c->local_codes && c->slabs == 1 && c->n_flushed == 0 && !c->pool_base &&
+           c->opt_flat_project && c->n > 0 && c->bins <= 255 &&
            (c->opt_early_vote == 2 || (c->n >= kEarlyMinGaussians && c->total_views >= kEarlyMinViews));
 }
+static bool early_possible(const Ctx* c) { return early_common(c) && c->total_views <= kMaxBatch && !c->wide; }
+// more than 255 announced views: the batches of labels_batched() (cut by the ANNOUNCED number of views) start their count
+// kernels on the second stream as soon as their views are staged; only the last batch, the totals and the tie walk are
+// left behind the last map
+static bool early_batched_possible(const Ctx* c) { return early_common(c) && c->total_views > kMaxBatch && c->opt_batched_counts; }
+static int early_batch_stage(Ctx* c);
 
 // Descriptors and culling planes of the views [lo, hi) -> e_views[lo..hi), culling block `block` of e_cull, on stream st.
 // dm: the projection variant these views allow.
-static int early_upload(Ctx* c, int lo, int hi, int block, hipStream_t st, int* dm) {
+static int early_upload(Ctx* c, int lo, int hi, int block, int blocks, hipStream_t st, int* dm) {
     const size_t vbytes = sizeof(ViewDesc) * kEarlyPitch, cbytes = sizeof(double) * kEarlyCullDoubles;
     if (!c->h_early) {
-        GSX_HIP(c, hipHostMalloc(&c->h_early, vbytes + 2 * cbytes, hipHostMallocDefault));
-        c->h_early_cap = vbytes + 2 * cbytes;
+        GSX_HIP(c, hipHostMalloc(&c->h_early, vbytes + cbytes, hipHostMallocDefault));
+        c->h_early_cap = vbytes + cbytes;
     }
-    GSX_HIP(c, c->e_views.ensure(vbytes));
-    GSX_HIP(c, c->e_cull.ensure(2 * cbytes));
+    // sized for the whole run at its first stage: a later stage must find the earlier ones' descriptors and planes in place
+    GSX_HIP(c, c->e_views.ensure(sizeof(ViewDesc) * (size_t)std::max(kEarlyPitch, c->total_views)));
+    GSX_HIP(c, c->e_cull.ensure(cbytes * (size_t)std::max(2, blocks)));
     if (!c->early_up_ev) GSX_HIP(c, hipEventCreateWithFlags(&c->early_up_ev, hipEventDisableTiming));
     else GSX_HIP(c, hipEventSynchronize(c->early_up_ev));  // the previous upload has left the staging buffer
-    ViewDesc* hv = static_cast<ViewDesc*>(c->h_early);
-    double* planes = reinterpret_cast<double*>(static_cast<char*>(c->h_early) + vbytes) + (size_t)block * kEarlyCullDoubles;
+    ViewDesc* hv = static_cast<ViewDesc*>(c->h_early);  // the stage's views, at most kEarlyPitch
+    double* planes = reinterpret_cast<double*>(static_cast<char*>(c->h_early) + vbytes);
     std::memset(planes, 0, cbytes);
     const long long base = (long long)reinterpret_cast<uintptr_t>(c->segpool.p);
     bool simple = true, coarse = true;
     for (int i = lo; i < hi; ++i) {
-        ViewDesc& v = hv[i];
+        ViewDesc& v = hv[i - lo];
         v = c->views[i];
         v.seg_off += base;
         simple = simple && v.unit_scale && v.seg_row_bytes;
@@ -1971,7 +1981,7 @@ static int early_upload(Ctx* c, int lo, int hi, int block, hipStream_t st, int* 
         for (int k = 0; k < kCullStride * kCullPlanes; ++k) planes[(size_t)k * kEarlyPitch + (i - lo)] = pl[k];
     }
     *dm = !simple ? kDivFlat : (coarse && c->opt_seg_coarse ? kDivFlatCoarse : kDivFlatSimple);
-    if (hi > lo) GSX_HIP(c, hipMemcpyAsync(c->e_views.as<ViewDesc>() + lo, hv + lo, sizeof(ViewDesc) * (size_t)(hi - lo), hipMemcpyHostToDevice, st));
+    if (hi > lo) GSX_HIP(c, hipMemcpyAsync(c->e_views.as<ViewDesc>() + lo, hv, sizeof(ViewDesc) * (size_t)(hi - lo), hipMemcpyHostToDevice, st));
     GSX_HIP(c, hipMemcpyAsync(c->e_cull.as<double>() + (size_t)block * kEarlyCullDoubles, planes, cbytes, hipMemcpyHostToDevice, st));
     GSX_HIP(c, hipEventRecord(c->early_up_ev, st));
     return GSX_OK;
@@ -1986,21 +1996,26 @@ static FusedParams early_params(Ctx* c, int lo, int hi, int block, int stride_by
     return p;
 }
 
+static int early_streams(Ctx* c) {
+    if (c->stream2) return GSX_OK;
+    // lowest priority: the kernels that expand the maps still arriving (c->stream) get the CUs the stage's waves free first
+    int least = 0, greatest = 0;
+    GSX_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    GSX_HIP(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
+    GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
+    GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
+    return GSX_OK;
+}
+
 static int early_vote_stage(Ctx* c) {
+    if (c->early_state == 0 && early_batched_possible(c)) return early_batch_stage(c);
     if (c->early_state != 0 || !early_possible(c)) return GSX_OK;
     const int nv = (int)c->views.size();
     const int at = std::max(1, (int)(((long long)c->total_views * c->opt_early_at + 999) / 1000));
     if (nv != at || at >= c->total_views) return GSX_OK;
     int rc = vote_flush_pending(c);  // the maps of these views are on their way on c->stream
     if (rc) return rc;
-    if (!c->stream2) {
-        // lowest priority: the kernels that expand the maps still arriving (c->stream) get the CUs the stage's waves free first
-        int least = 0, greatest = 0;
-        GSX_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        GSX_HIP(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
-        GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
-        GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
-    }
+    if ((rc = early_streams(c))) return rc;
     const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
     GSX_HIP(c, c->ecnt.ensure(plane + kEarlySlack));
     GSX_HIP(c, c->efv.ensure(plane + kEarlySlack));
@@ -2009,7 +2024,7 @@ static int early_vote_stage(Ctx* c) {
     GSX_HIP(c, hipEventRecord(c->early_maps_ev, c->stream));
     GSX_HIP(c, hipStreamWaitEvent(c->stream2, c->early_maps_ev, 0));
     int dm = kDivFlat;
-    if ((rc = early_upload(c, 0, at, 0, c->stream2, &dm))) return rc;
+    if ((rc = early_upload(c, 0, at, 0, 2, c->stream2, &dm))) return rc;
     FusedParams p = early_params(c, 0, at, 0, 2);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
     auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
@@ -2029,13 +2044,47 @@ static int early_vote_stage(Ctx* c) {
     return GSX_OK;
 }
 
+static int early_batch_stage(Ctx* c) {
+    const int nv = (int)c->views.size();
+    const int S = (c->total_views + kMaxBatch - 1) / kMaxBatch;
+    const int s = c->early_batches;
+    if (s >= S - 1) return GSX_OK;  // the last batch ends with the last view: vote_finalize launches it
+    const int lo = (int)((long long)c->total_views * s / S), hi = (int)((long long)c->total_views * (s + 1) / S);
+    if (nv != hi) return GSX_OK;
+    int rc = vote_flush_pending(c);
+    if (rc) return rc;
+    if ((rc = early_streams(c))) return rc;
+    const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
+    GSX_HIP(c, c->bcnt.ensure(plane * S));  // all batches at the first stage: a later one must find the earlier planes in place
+    if ((rc = ensure_tally(c))) return rc;
+    GSX_HIP(c, hipEventRecord(c->early_maps_ev, c->stream));
+    GSX_HIP(c, hipStreamWaitEvent(c->stream2, c->early_maps_ev, 0));
+    int dm = kDivFlat;
+    if ((rc = early_upload(c, lo, hi, s, S, c->stream2, &dm))) return rc;
+    FusedParams p = early_params(c, lo, hi, s, 1);
+    const size_t lds = (size_t)kBlock * p.stride_dw * 4;
+    auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+             : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
+                                    : vote_fused_counts_kernel<kUnroll, kDivFlat>;
+    if ((rc = set_lds(c, k, lds))) return rc;
+    {
+        ProfScope ps(c, "vote_early_counts", c->stream2);
+        hipLaunchKernelGGL(k, dim3(grid_for(c->n)), dim3(kBlock), lds, c->stream2, p, p.views, c->bcnt.as<uint8_t>() + plane * s, (long long)c->n_pad);
+        GSX_HIP(c, hipGetLastError());
+    }
+    GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+    c->early_batches = s + 1;
+    c->early_done = hi;
+    return GSX_OK;
+}
+
 // vote_finalize behind an early stage: the views [early_done, nv) on top of the early planes -> c->labels
 static int early_vote_finish(Ctx* c) {
     const int nv = (int)c->views.size();
     int rc = vote_flush_pending(c);
     if (rc) return rc;
     int dm = kDivFlat;
-    if ((rc = early_upload(c, c->early_done, nv, 1, c->stream, &dm))) return rc;
+    if ((rc = early_upload(c, c->early_done, nv, 1, 2, c->stream, &dm))) return rc;
     GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
     FusedParams p = early_params(c, c->early_done, nv, 1, 1);
     const size_t lds = (size_t)(kBlock / 64) * ((c->bins + 3) / 4) * 256;  // per wave: [bin][64] bytes, rows padded to a multiple of four
@@ -2317,7 +2366,13 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
         p.nviews = hi - lo;
         if (p.cull) p.cull = base.cull + lo;
     };
-    for (int s = 0; s < S; ++s) {
+    // batches whose count kernels already ran on the second stream while the run's later maps were handed over (early_batch_stage:
+    // same batches - the run brought exactly the announced views -, same planes, the whole scene)
+    const bool early = c->early_batches > 0 && c->early_state == 0 && early_batched_possible(c) && nv == c->total_views && r.i0 == 0 &&
+                       r.n == c->n;
+    const int s0 = early ? c->early_batches : 0;
+    if (early) GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+    for (int s = s0; s < S; ++s) {
         FusedParams p;
         batch(s, p);
         ProfScope ps(c, "vote_fused_counts");

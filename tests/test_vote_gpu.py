@@ -425,6 +425,38 @@ def test_more_than_255_views_on_one_gpu(gsx):
         assert len(np.unique(want)) > 3
 
 
+def test_early_count_batches_with_more_than_255_views(gsx):
+    """More than 255 announced views with the early vote on: every batch but the last starts its count kernel on the second
+    stream as soon as its views are staged.  Same labels as the oracle; a caller that stops before the announced number of
+    views falls back to batches cut by the views that came; the flat_project = 0 kernels never start early."""
+    n = 50_000
+    for V, stop, opts in ((311, None, {}), (700, None, {"wave_cull": 0}), (520, 400, {}), (300, None, {"flat_project": 0}), (256, None, {"seg_coarse": 0})):
+        pos, cams, _ = scene.make_scene(n, V, 160, 96, config_id=33, convention="w2c")
+        segs = [scene.make_segmap(96, 160, 6, 9500 + v, n_sites=12, cell=int(1 + v % 4)) for v in range(V)]
+        sizes = [(160, 96)] * V
+        m = V if stop is None else stop
+        want = oracle.assign_labels(pos, cams[:m], segs[:m], sizes[:m], threads=0)
+        with gsx.Context(0) as c:
+            c.set_option("early_vote", 2)
+            for k, v in opts.items():
+                c.set_option(k, v)
+            c.profile(True)
+            c.upload_positions(pos)
+            c.vote_begin(6, 0, V)
+            for v in range(m):
+                c.vote_view(cams[v], segs[v], sizes[v])
+            S = -(-V // 255)
+            started = 0 if opts.get("flat_project") == 0 else sum(1 for b in range(S - 1) if V * (b + 1) // S <= m)
+            assert c.vote_early_views() == (V * started // S if started else 0)
+            got = c.vote_finalize()
+            assert np.array_equal(got, want), (V, stop, opts)
+            assert _kernel_launches(c, "vote_early_counts") == started
+            used = started if m == V else 0      # early planes are only used when the run brought the announced views
+            assert _kernel_launches(c, "vote_fused_counts") == -(-m // 255) - used, (V, stop, opts)
+            c.vote_rewind()
+            assert np.array_equal(c.vote_finalize(), want), (V, stop, opts, "one piece")
+
+
 def test_view_sharding_exchange_on_one_gpu(gsx, ctx):
     """Two contexts play two ranks; the two all-reduces are done by hand on the host."""
     n, V = 30_000, 10
