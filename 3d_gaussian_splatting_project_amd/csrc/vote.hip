@@ -957,11 +957,19 @@ __global__ __launch_bounds__(kBlock) void vote_slab_totals_kernel(const uint8_t*
 // v3, every rank: for each TIED Gaussian (two or more candidate bins) walk this rank's views in FORWARD order
 // and stop at the first one that votes a candidate: code = (255 - local view index) << 8 | bin, 0 if none.
 // cand_all: [S][kCandWords][sn] (all-gathered masks); codes: u16 [S][sn], slab-major.
+// earlier: codes of n_earlier batches that come BEFORE this one in view order and were walked before it (one GPU playing the
+// ranks one after the other): a Gaussian one of them has resolved is not walked again - the earliest batch wins anyway.
 __global__ __launch_bounds__(kBlock) void vote_tie_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                           const uint32_t* __restrict__ cand_all, long long sn,
-                                                          uint16_t* __restrict__ codes) {
+                                                          uint16_t* __restrict__ codes, const uint16_t* __restrict__ earlier,
+                                                          int n_earlier) {
     const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     if (i >= p.n) return;
+    for (int e = 0; e < n_earlier; ++e)
+        if (earlier[(long long)e * sn + i]) {  // (single slab: codes are [batch][sn])
+            codes[i] = 0;
+            return;
+        }
     const long long slab = i / sn, j = i - slab * sn;
     uint32_t mask[kCandWords];
     int pop = 0;
@@ -2389,7 +2397,7 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
         batch(s, p);
         ProfScope ps(c, "vote_tie");
         hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(r.n)), dim3(kBlock), 0, c->stream, p, p.views, c->cand.as<uint32_t>(), npad,
-                           c->bcodes.as<uint16_t>() + (size_t)npad * s);
+                           c->bcodes.as<uint16_t>() + (size_t)npad * s, c->bcodes.as<uint16_t>(), s);
     }
     {
         ProfScope ps(c, "vote_tie_resolve");
@@ -2594,7 +2602,7 @@ int vote_tie_codes(Ctx* c, const void* cand_all) {
         FusedParams p = fused_params(c, 1);
         ProfScope ps(c, "vote_tie");
         hipLaunchKernelGGL(vote_tie_kernel, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream, p, p.views,
-                           (const uint32_t*)cand_all, (long long)c->sn, c->codes.as<uint16_t>());
+                           (const uint32_t*)cand_all, (long long)c->sn, c->codes.as<uint16_t>(), (const uint16_t*)nullptr, 0);
         GSX_HIP(c, hipGetLastError());
     }
     return GSX_OK;  // ordered by the ctx stream; nothing waits on the host

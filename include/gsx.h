@@ -100,7 +100,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "early_vote"   (default 1)  a run whose views all arrive on this context through gsx_vote_view (first_view 0, at most
  *                               255 announced, >= 32 of them, >= 2^18 Gaussians) votes its first views on a second stream
  *                               while the host is still handing over the rest; gsx_vote_finalize then walks only the views
- *                               behind them on top of the early counts.  Same labels, bit for bit.  0 = off, 2 = whatever
+ *                               behind them on top of the early counts (with more than 255 announced views: every batch of
+ *                               <= 255 views but the last starts its count kernel when it is staged).  Same labels, bit for bit.  0 = off, 2 = whatever
  *                               the run's size (tests).  "early_vote_at" (default 700): the stage starts when this many
  *                               permille of the announced views are staged
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
