@@ -180,6 +180,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         if (value < 2 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: render_phase_ratio must be in [2,64]");
         c->opt_render_phase_ratio = (int)value;
     }
+    else if (k == "render_frames") {
+        if (value < 1 || value > Ctx::kMaxFrames) return gsx::fail(c, GSX_E_INVALID, "set_option: render_frames must be in [1,%d]", (int)Ctx::kMaxFrames);
+        c->opt_render_frames = (int)value;
+    }
     else if (k == "blend_pk2") c->opt_blend_pk2 = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "exchange_slabs") {
         if (value < 1 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: exchange_slabs must be in [1,64]");

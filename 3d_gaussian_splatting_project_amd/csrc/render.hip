@@ -937,25 +937,25 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     return GSX_OK;
 }
 
-// ---- several views: two frames in flight --------------------------------------------------------------------------------
+// ---- several views: a few frames in flight ------------------------------------------------------------------------------
 // A frame is a chain of dependent kernels: memory-bound per-splat passes and sorts first, then the VALU-bound blend with
-// its tail of long tiles.  Two frames on two HIP streams fill each other's gaps (measured 916 -> 1221 views/s at 3 M
-// splats / 1080p / SH 3).  The context therefore keeps a TWIN: a second stream with its own per-frame buffers that
-// aliases this context's scene (texel pairs, SH planes: nothing is duplicated), driven by a second host thread; even
-// frames are rendered here, odd frames on the twin.
-static int twin_sync_scene(Ctx* c) {
-    if (!c->twin) {
-        c->twin = new (std::nothrow) Ctx();
-        if (!c->twin) return fail(c, GSX_E_INVALID, "render_views: out of host memory");
-        c->twin->device = c->device;
-        hipError_t e = hipStreamCreateWithFlags(&c->twin->stream, hipStreamNonBlocking);
+// its tail of long tiles.  Frames on separate HIP streams fill each other's gaps (measured 916 -> 1221 views/s with two at
+// 3 M splats / 1080p / SH 3).  The context therefore keeps TWINS: further streams with their own per-frame buffers that
+// alias this context's scene (texel pairs, SH planes: nothing is duplicated), each driven by a host thread of its own; frame
+// k is rendered by stream k % F (option "render_frames").
+static int twin_sync_scene(Ctx* c, int k) {
+    if (!c->twins[k]) {
+        c->twins[k] = new (std::nothrow) Ctx();
+        if (!c->twins[k]) return fail(c, GSX_E_INVALID, "render_views: out of host memory");
+        c->twins[k]->device = c->device;
+        hipError_t e = hipStreamCreateWithFlags(&c->twins[k]->stream, hipStreamNonBlocking);
         if (e != hipSuccess) {
-            delete c->twin;
-            c->twin = nullptr;
+            delete c->twins[k];
+            c->twins[k] = nullptr;
             return fail(c, GSX_E_HIP, "render_views: hipStreamCreate failed: %s", hipGetErrorString(e));
         }
     }
-    Ctx* t = c->twin;
+    Ctx* t = c->twins[k];
     t->r_tex.alias(c->r_tex);
     t->r_shc.alias(c->r_shc);
     t->rn = c->rn;
@@ -971,22 +971,24 @@ static int twin_sync_scene(Ctx* c) {
 }
 
 void render_release_twin(Ctx* c) {
-    Ctx* t = c->twin;
-    if (!t) return;
-    (void)hipStreamSynchronize(t->stream);
-    for (DevBuf* b : {&t->r_tex, &t->r_shc, &t->r_image, &t->r_ranges, &t->r_small, &t->r_scan, &t->r_depth, &t->r_bucket, &t->r_rect,
-                      &t->r_count, &t->r_offset, &t->r_rec0, &t->r_rec1, &t->r_rec2, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
-                      &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist})
-        b->release();
-    (void)hipStreamDestroy(t->stream);
-    delete t;
-    c->twin = nullptr;
+    for (Ctx*& t : c->twins) {
+        if (!t) continue;
+        (void)hipStreamSynchronize(t->stream);
+        for (DevBuf* b : {&t->r_tex, &t->r_shc, &t->r_image, &t->r_ranges, &t->r_small, &t->r_scan, &t->r_depth, &t->r_bucket, &t->r_rect,
+                          &t->r_count, &t->r_offset, &t->r_rec0, &t->r_rec1, &t->r_rec2, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
+                          &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist})
+            b->release();
+        (void)hipStreamDestroy(t->stream);
+        delete t;
+        t = nullptr;
+    }
 }
 
 int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* const* rgba_out) {
     if (n < 0 || (n > 0 && !cams)) return fail(c, GSX_E_INVALID, "render_views: bad arguments");
     if (n == 0) return GSX_OK;
-    if (n == 1 || c->prof_on)  // the per-kernel events belong to one stream: profiled runs render one frame at a time
+    const int F = std::max(1, std::min({c->opt_render_frames, (int)Ctx::kMaxFrames, n}));
+    if (F == 1 || c->prof_on)  // the per-kernel events belong to one stream: profiled runs render one frame at a time
     {
         unsigned long long P = 0, used = 0;
         for (int k = 0; k < n; ++k) {
@@ -999,40 +1001,52 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         c->r_consumed = used;
         return GSX_OK;
     }
-    int rc = twin_sync_scene(c);
-    if (rc) return rc;
-    Ctx* t = c->twin;
-    int rc_twin = GSX_OK;
-    unsigned long long P[2] = {0, 0}, used[2] = {0, 0};
-    std::thread other([&] {
-        try {  // nothing may escape a thread's entry function
-            (void)hipSetDevice(t->device);
-            for (int k = 1; k < n && rc_twin == GSX_OK; k += 2) {
-                rc_twin = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
-                P[1] += t->r_P;
-                used[1] += t->r_consumed;
-            }
-        } catch (...) {
-            rc_twin = fail(t, GSX_E_INVALID, "render_views: the second stream's host thread failed (out of host memory?)");
+    int rc = GSX_OK;
+    for (int f = 1; f < F; ++f)
+        if ((rc = twin_sync_scene(c, f - 1))) return rc;
+    // frame k is rendered by stream k % F: stream 0 is the context's own (this thread), the others have a host thread each
+    int rcs[Ctx::kMaxFrames] = {GSX_OK, GSX_OK, GSX_OK, GSX_OK};
+    unsigned long long P[Ctx::kMaxFrames] = {0, 0, 0, 0}, used[Ctx::kMaxFrames] = {0, 0, 0, 0};
+    auto frames_of = [&](Ctx* t, int f) {
+        for (int k = f; k < n && rcs[f] == GSX_OK; k += F) {
+            rcs[f] = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
+            P[f] += t->r_P;
+            used[f] += t->r_consumed;
         }
-    });
+    };
+    std::thread others[Ctx::kMaxFrames - 1];
+    int started = 0;
     try {
-        for (int k = 0; k < n && rc == GSX_OK; k += 2) {
-            rc = render_view(c, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
-            P[0] += c->r_P;
-            used[0] += c->r_consumed;
+        for (int f = 1; f < F; ++f) {
+            Ctx* t = c->twins[f - 1];
+            others[f - 1] = std::thread([&, t, f] {
+                try {  // nothing may escape a thread's entry function
+                    (void)hipSetDevice(t->device);
+                    frames_of(t, f);
+                } catch (...) {
+                    rcs[f] = fail(t, GSX_E_INVALID, "render_views: a stream's host thread failed (out of host memory?)");
+                }
+            });
+            ++started;
         }
+        frames_of(c, 0);
     } catch (...) {
-        other.join();  // never leave a joinable thread behind
+        for (int f = 0; f < started; ++f) others[f].join();  // never leave a joinable thread behind
         throw;
     }
-    other.join();
-    if (rc == GSX_OK && rc_twin != GSX_OK) {
-        c->err = t->err;
-        rc = rc_twin;
+    for (int f = 0; f < started; ++f) others[f].join();
+    rc = rcs[0];
+    for (int f = 1; f < F && rc == GSX_OK; ++f)
+        if (rcs[f] != GSX_OK) {
+            c->err = c->twins[f - 1]->err;
+            rc = rcs[f];
+        }
+    c->r_P = 0;
+    c->r_consumed = 0;
+    for (int f = 0; f < F; ++f) {
+        c->r_P += P[f];
+        c->r_consumed += used[f];
     }
-    c->r_P = P[0] + P[1];
-    c->r_consumed = used[0] + used[1];
     return rc;
 }
 

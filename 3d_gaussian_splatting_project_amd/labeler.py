@@ -360,8 +360,9 @@ class Context:
         return out
 
     def render_views(self, cameras, width, height, to_host=True):
-        """Several frames of one size, two in flight on two HIP streams (gsx_render_views) -> (n, height, width, 4)
-        float32, or None with to_host=False.  Same pixels as render_view, about a third more views per second."""
+        """Several frames of one size, up to four in flight on HIP streams of their own (gsx_render_views, option
+        render_frames) -> (n, height, width, 4) float32, or None with to_host=False.  Same pixels as render_view, about half
+        as many views per second again."""
         cams = (Camera * len(cameras))(*[c if isinstance(c, Camera) else Camera.from_dict(c) for c in cameras])
         out = np.empty((len(cameras), height, width, 4), np.float32) if to_host else None
         ptrs = (C.c_void_p * len(cameras))(*[out[k].ctypes.data for k in range(len(cameras))]) if to_host else None

@@ -112,7 +112,7 @@ def make_segmaps(scene, torch, device, H, W, classes, seeds, cell):
 
 def render_leg(pkg, ctx, args, W, H):
     """Forward rasterizer on the same kind of scene (SH degree 3, viewer camera convention): views/s through
-    gsx_render_views (two frames in flight on two HIP streams inside one context) and one frame at a time, both timed
+    gsx_render_views (four frames in flight on HIP streams of their own inside one context) and one frame at a time, both timed
     WITHOUT the per-kernel events (they serialise the launches); then per-kernel HIP-event times and the blend kernel's
     algorithmic bytes / time."""
     scene = pkg.scene
@@ -155,7 +155,7 @@ def render_leg(pkg, ctx, args, W, H):
     achieved = alg / (blend_ms * 1e-3) / 1e9 if blend_ms > 0 else None
     return {"views": len(cams), "splats": n, "sh_degree": 3, "width": W, "height": H,
             "views_per_s": round(len(cams) / dt, 2), "gaussian_views_per_s": round(n * len(cams) / dt, 1),
-            "views_per_s_note": "gsx_render_views: two frames in flight on two HIP streams of one context",
+            "views_per_s_note": "gsx_render_views: four frames in flight on four HIP streams of one context (option render_frames)",
             "views_per_s_one_frame_at_a_time": round(len(cams) / dt_one, 2),
             "tile_splat_pairs_per_view": int(P), "pairs_consumed_per_view": int(Pc), "kernel_ms_per_view": k_ms,
             "kernel_ms_sum_per_view": round(sum(k_ms.values()), 4),

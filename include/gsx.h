@@ -12,7 +12,7 @@
  *   - host pointers are read/written during the call only; the library never keeps them.
  *   - device pointers returned by *_device() accessors stay valid until the next gsx_vote_begin /
  *     gsx_upload_* on the same ctx, and belong to the ctx.
- *   - one ctx = one GPU = one HIP stream (gsx_render_views adds a second, internal one); a ctx is used from one host
+ *   - one ctx = one GPU = one HIP stream (gsx_render_views and the early vote add internal ones); a ctx is used from one host
  *     thread at a time; the library runs its own worker threads for host-side packing and the second render stream.
  *   - there is NO CPU fallback: without a gfx950 device gsx_create fails with GSX_E_HIP.
  */
@@ -315,12 +315,13 @@ int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* sc
 int gsx_upload_sh(gsx_ctx* ctx, const float* f_rest, int32_t sh_degree);
 int64_t gsx_num_splats(const gsx_ctx* ctx);
 int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out);
-/* n views of one size, two frames in flight: the context keeps a second HIP stream with its own per-frame buffers that
- * shares the uploaded scene, and renders even views on its own stream and odd views on the second one from a second
- * host thread - the memory-bound front of one frame overlaps the VALU-bound blend tail of the other (3 M splats / 1080p /
- * SH 3: 916 views/s one at a time -> ~1200).  Same pixels as gsx_render_view.  rgba_out: NULL, or n pointers (each NULL
- * or height x width x 4 floats).  Afterwards gsx_render_num_pairs* report the SUMS over the n views and
- * gsx_render_image_device the last EVEN view.  With profiling enabled the views are rendered one at a time. */
+/* n views of one size, F frames in flight (option "render_frames", default 4, 1..4): the context keeps F - 1 further HIP
+ * streams with their own per-frame buffers that share the uploaded scene, and renders view k on stream k % F, each further
+ * stream from a host thread of its own - the memory-bound front of one frame overlaps the VALU-bound blend tail of the
+ * others (3 M splats / 1080p / SH 3: 935 views/s one at a time, 1252 / 1359 / 1396 with 2 / 3 / 4 in flight).  Same pixels
+ * as gsx_render_view.  rgba_out: NULL, or n pointers (each NULL or height x width x 4 floats).  Afterwards
+ * gsx_render_num_pairs* report the SUMS over the n views and gsx_render_image_device the last view of the context's own
+ * stream (the last k with k % F == 0).  With profiling enabled the views are rendered one at a time. */
 int gsx_render_views(gsx_ctx* ctx, int32_t n, const gsx_camera* cams, int32_t width, int32_t height, float* const* rgba_out);
 void* gsx_render_image_device(gsx_ctx* ctx);
 /* number of (tile, splat) pairs the last gsx_render_view sorted and blended */
