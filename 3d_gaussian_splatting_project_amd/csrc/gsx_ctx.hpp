@@ -250,8 +250,8 @@ struct Ctx {
     int opt_render_phases = 2;           // depth phases per frame (1 = bin and sort every pair at once)
     int opt_render_phase_ratio = 4;      // phase p ends at n / ratio^(K-1-p) splats (front to back)
     unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
-    static constexpr int kMaxFrames = 4;
-    Ctx* twins[kMaxFrames - 1] = {nullptr, nullptr, nullptr};  // gsx_render_views: further streams + per-frame buffers, aliasing this context's scene
+    static constexpr int kMaxFrames = 6;
+    Ctx* twins[kMaxFrames - 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // gsx_render_views: further streams + per-frame buffers, aliasing this context's scene
     int opt_render_frames = 4;           // frames in flight in gsx_render_views (1 .. kMaxFrames): 935 / 1252 / 1359 / 1396 views/s with 1 / 2 / 3 / 4
     size_t r_pair_cap = 0;               // capacity (pairs) of r_keys*/r_vals*: grown when a phase overflows it, the frame is redone
     unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)

@@ -1005,8 +1005,8 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
     for (int f = 1; f < F; ++f)
         if ((rc = twin_sync_scene(c, f - 1))) return rc;
     // frame k is rendered by stream k % F: stream 0 is the context's own (this thread), the others have a host thread each
-    int rcs[Ctx::kMaxFrames] = {GSX_OK, GSX_OK, GSX_OK, GSX_OK};
-    unsigned long long P[Ctx::kMaxFrames] = {0, 0, 0, 0}, used[Ctx::kMaxFrames] = {0, 0, 0, 0};
+    int rcs[Ctx::kMaxFrames] = {};  // GSX_OK == 0
+    unsigned long long P[Ctx::kMaxFrames] = {}, used[Ctx::kMaxFrames] = {};
     auto frames_of = [&](Ctx* t, int f) {
         for (int k = f; k < n && rcs[f] == GSX_OK; k += F) {
             rcs[f] = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);

@@ -315,7 +315,7 @@ int gsx_upload_splats(gsx_ctx* ctx, int64_t n, const float* xyz, const float* sc
 int gsx_upload_sh(gsx_ctx* ctx, const float* f_rest, int32_t sh_degree);
 int64_t gsx_num_splats(const gsx_ctx* ctx);
 int gsx_render_view(gsx_ctx* ctx, const gsx_camera* cam, int32_t width, int32_t height, float* rgba_out);
-/* n views of one size, F frames in flight (option "render_frames", default 4, 1..4): the context keeps F - 1 further HIP
+/* n views of one size, F frames in flight (option "render_frames", default 4, 1..6; five and six measured slower than four): the context keeps F - 1 further HIP
  * streams with their own per-frame buffers that share the uploaded scene, and renders view k on stream k % F, each further
  * stream from a host thread of its own - the memory-bound front of one frame overlaps the VALU-bound blend tail of the
  * others (3 M splats / 1080p / SH 3: 935 views/s one at a time, 1252 / 1359 / 1396 with 2 / 3 / 4 in flight).  Same pixels
