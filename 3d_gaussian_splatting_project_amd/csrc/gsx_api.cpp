@@ -202,7 +202,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         if (value < 0 || value > 2) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote must be 0, 1 or 2");
         c->opt_early_vote = (int)value;
     } else if (k == "early_vote_at") {
-        if (value < 1 || value > 1000) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote_at must be in [1,1000] (permille of the announced views)");
+        if (value < 0 || value > 1000) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote_at must be in [0,1000] (permille of the announced views; 0 = from the hand-over rate)");
         c->opt_early_at = (int)value;
     }
     else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);

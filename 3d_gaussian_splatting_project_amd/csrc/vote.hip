@@ -31,6 +31,9 @@
 //   order) is earliest among the max-count labels is the last one to do so.  See DESIGN.md §3.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cmath>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1945,6 +1948,7 @@ FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
 static constexpr int kEarlyPitch = 256;                    // views per block of culling planes (>= kMaxBatch)
 static constexpr long long kEarlyMinGaussians = 1 << 18;   // below this the vote is too short to be worth a second stream
 static constexpr int kEarlyMinViews = 32;
+static constexpr double kEarlyUsPerGaussianView = 4.4e-6;  // early stage on MI355X: 1.6 ms for 3 M Gaussians x 140 views, + 15 %
 static constexpr size_t kEarlySlack = 64 * 260;           // the last stage reads whole groups of four rows, up to row 4 * kRegRows - 1, whatever the bin count
 static constexpr size_t kEarlyCullDoubles = (size_t)kCullStride * kCullPlanes * kEarlyPitch;
 
@@ -2019,8 +2023,25 @@ static int early_vote_stage(Ctx* c) {
     if (c->early_state == 0 && early_batched_possible(c)) return early_batch_stage(c);
     if (c->early_state != 0 || !early_possible(c)) return GSX_OK;
     const int nv = (int)c->views.size();
-    const int at = std::max(1, (int)(((long long)c->total_views * c->opt_early_at + 999) / 1000));
-    if (nv != at || at >= c->total_views) return GSX_OK;
+    int at;
+    if (c->opt_early_at > 0) {
+        at = std::max(1, (int)(((long long)c->total_views * c->opt_early_at + 999) / 1000));
+        if (nv != at) return GSX_OK;
+    } else {
+        // The split that lets the stage finish just as the last map arrives: it walks a view in about kEarlyUsPerGaussianView * n
+        // microseconds, the caller hands over a map every t_map (measured on this run's own calls) - so E / V = t_map / (t_map +
+        // that).  Kept between one half and 88 % of the announced views; the stage starts at the first call past it.
+        const auto now = std::chrono::steady_clock::now();
+        if (nv == 1) c->early_t0 = now;
+        if (nv < std::max(8, c->total_views / 4)) return GSX_OK;
+        const double t_map = std::chrono::duration<double, std::micro>(now - c->early_t0).count() / (double)(nv - 1);
+        const double t_view = kEarlyUsPerGaussianView * (double)c->n;
+        const int lo = (c->total_views + 1) / 2, hi = (int)(((long long)c->total_views * 880) / 1000);
+        const int want = std::min(std::max((int)std::ceil(c->total_views * t_map / (t_map + t_view)), lo), std::max(lo, hi));
+        if (nv < want) return GSX_OK;
+        at = nv;
+    }
+    if (at >= c->total_views) return GSX_OK;
     int rc = vote_flush_pending(c);  // the maps of these views are on their way on c->stream
     if (rc) return rc;
     if ((rc = early_streams(c))) return rc;

@@ -102,8 +102,9 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               while the host is still handing over the rest; gsx_vote_finalize then walks only the views
  *                               behind them on top of the early counts (with more than 255 announced views: every batch of
  *                               <= 255 views but the last starts its count kernel when it is staged).  Same labels, bit for bit.  0 = off, 2 = whatever
- *                               the run's size (tests).  "early_vote_at" (default 700): the stage starts when this many
- *                               permille of the announced views are staged
+ *                               the run's size (tests).  "early_vote_at": the stage starts when this many permille of the
+ *                               announced views are staged; 0 (default): chosen from the run's own hand-over rate so
+ *                               that the stage ends as the last map arrives (between 50 and 88 %)
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce

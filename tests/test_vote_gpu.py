@@ -241,9 +241,14 @@ def test_early_vote_on_a_large_scene(gsx):
     assert (want != -1).mean() > 0.5
     with gsx.Context(0) as c:
         c.profile(True)
-        got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+        got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()      # split point chosen from the hand-over rate
         assert np.array_equal(got, want)
         assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 0
+        assert V // 2 <= c.vote_early_views() <= V * 88 // 100
+        c.set_option("early_vote_at", 700)
+        assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want) and c.vote_early_views() == 28
+        c.profile(True)
+        assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want)
         c.set_option("early_vote", 0)
         assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want)
         assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 1

@@ -55,13 +55,14 @@ def measure(tag):
 
 ctx.set_option("early_vote", 0)
 ref = measure("one piece      ")
-for at in (650,):
+for at in (0, 700, 0):   # 0: split point from the hand-over rate
     ctx.set_option("early_vote", 1)
     ctx.set_option("early_vote_at", at)
     got = measure(f"early at {at:4d}")
+    print(f"    early views {ctx.vote_early_views()}", flush=True)
     assert np.array_equal(got, ref), at
 ctx.set_option("early_vote_at", 700)
-for ab in (16, 32, 64, 128, 256, 512, 32 + 64, 32 + 64 + 128 + 256 + 512, 0):     # timing only, see vote.hip early_vote_finish
+for ab in (32, 0):     # timing only, see vote.hip early_vote_finish
     ctx.set_option("ablate", ab)
     measure(f"at 700 ablate {ab:4d}")
 # the last stage alone, back to back (the run's early planes are still there): what the kernel costs when nothing else runs
