@@ -979,7 +979,7 @@ def test_randomised_small_configurations(gsx):
         for trial in range(40):
             n = int(rng.integers(1, 3000))
             V = int(rng.integers(1, 12))
-            C = int(rng.choice([1, 2, 7, 80, 150, 255]))
+            C = int(rng.choice([1, 2, 7, 80, 150, 200, 255]))   # 200: more than 152 bins, the last stage of the early vote takes its any-bin-count form
             c.set_option("spatial_sort", int(rng.integers(0, 2)))
             c.set_option("seg_tiled", int(rng.integers(0, 2)))
             c.set_option("vote_unroll", int(rng.choice([2, 4, 8])))
