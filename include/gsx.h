@@ -115,6 +115,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               blend consumes instead of all of them (3 M splats @1080p: 23.3 M pairs -> 7.2 M with 2
  *                               phases, 2.2 M consumed).  What is skipped could not have moved a channel by 1e-5
  *   "render_phase_ratio" (default 4)  phase p ends after n / ratio^(K-1-p) splats of the depth order (2..64)
+ *   "render_frames" (default 4) gsx_render_views: frames in flight, each on a HIP stream of its own (1..6; 935 / 1252 /
+ *                               1359 / 1396 / 1296 / 1349 views/s with 1..6 at 3 M splats @1080p SH 3)
  *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
  *                               (minimum of the quadratic over the tile), not its whole bounding box.  The binning
  *                               is wave-cooperative (no lane walks a rectangle on its own), yet on the 3 M-splat
