@@ -201,7 +201,8 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "early_vote") {
         if (value < 0 || value > 2) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote must be 0, 1 or 2");
         c->opt_early_vote = (int)value;
-    } else if (k == "early_vote_at") {
+    } else if (k == "early_replay") c->opt_early_replay = value != 0;
+    else if (k == "early_vote_at") {
         if (value < 0 || value > 1000) return gsx::fail(c, GSX_E_INVALID, "set_option: early_vote_at must be in [0,1000] (permille of the announced views; 0 = from the hand-over rate)");
         c->opt_early_at = (int)value;
     }

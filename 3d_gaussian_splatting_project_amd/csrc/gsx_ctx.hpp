@@ -223,6 +223,8 @@ struct Ctx {
     int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
     int opt_early_at = 0;        // the stage starts when this many permille of the announced views are staged; 0: chosen from the run's own hand-over rate
     std::chrono::steady_clock::time_point early_t0;  // first gsx_vote_view of the run
+    int opt_early_replay = 0;    // 1: the early stage only records the votes, the last stage replays them (vote_record_kernel / vote_fused_replay_kernel)
+    bool early_replayed = false; // this run's early stage was a record-only one
     int early_state = 0;         // 0: not started in this run, 1: started, -1: not available any more (rewind, pool moved)
     int early_done = 0;          // views [0, early_done) are in ecnt / efv (or, > 255 announced views, in the first early_batches planes of bcnt)
     int early_batches = 0;       // > 255 announced views: batches of labels_batched() whose count kernels already ran on stream2

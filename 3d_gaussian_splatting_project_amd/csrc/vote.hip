@@ -707,6 +707,98 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 // The planes are read as dwords by a transposed lane mapping (lane (g, t) = bins g, g+4, .. of Gaussians 4t .. 4t+3,
 // as the planes kernel stores them): 256 B per wave instruction instead of 64 single bytes.
 // -------------------------------------------------------------------------------------------------
+// ---- early vote by RECORD and REPLAY (option "early_replay") -----------------------------------------------------------------
+// The early stage only RECORDS the vote of every Gaussian in every early view (bin + 1, 0 = none; [wave][view][64 lanes]
+// bytes): projection, gather, store - no histogram, no LDS, twice the waves per CU.  The last stage is the one-piece kernel
+// with one difference: behind its reverse walk over the views [E, V) it does not project the views E-1 .. 0, it reads their
+// votes back from the record, in the same reverse order.  Every update of the histogram and of (best, best_count) is the
+// one the one-piece kernel would have made: the labels are identical by construction.
+template <int U, int DIV>
+__global__ __launch_bounds__(kBlock) void vote_record_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                             uint8_t* __restrict__ rec) {
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const long long ic = valid ? i : 0;
+    const float xf = p.x[ic], yf = p.y[ic], zf = p.z[ic];
+    const double X = valid ? (double)xf : __builtin_nan("");  // lanes past the end never vote
+    const double Y = valid ? (double)yf : 0.0;
+    const double Z = valid ? (double)zf : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+    const int lane = threadIdx.x & 63;
+    uint8_t* r = rec + (i - lane) * p.nviews + lane;
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
+        int bin[U];
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (kFull || vb - 1 - u >= 0) r[(vb - 1 - u) * 64] = (uint8_t)(bin[u] + 1);
+    };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
+}
+
+template <int U, int DIV>
+__global__ __launch_bounds__(kBlock) void vote_fused_replay_kernel(FusedParams p, const ViewDesc* __restrict__ views,
+                                                                   const uint8_t* __restrict__ rec, int E,
+                                                                   int* __restrict__ labels) {
+    extern __shared__ uint32_t lds[];
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    uint8_t* h = reinterpret_cast<uint8_t*>(row);
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
+    const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
+    const bool valid = i < p.n;
+    const long long ic = valid ? i : 0;
+    const float xf = p.x[ic], yf = p.y[ic], zf = p.z[ic];
+    const double X = valid ? (double)xf : __builtin_nan("");
+    const double Y = valid ? (double)yf : 0.0;
+    const double Z = valid ? (double)zf : 0.0;
+    const uint8_t* __restrict__ pool = p.pool;
+    int best = -1, bestc = 0;
+    auto vote = [&](int b) {  // dls.py:295, :303 in reverse view order, as in vote_fused_labels_kernel
+        const int c = h[b] + 1;
+        h[b] = (uint8_t)c;
+        if (c >= bestc) {
+            bestc = c;
+            best = b;
+        }
+    };
+    const CullMasks cmask = wave_cull_masks(p.cull, p.cull_pitch, p.nviews, X, Y, Z, p.cull_tally);
+    auto chunk = [&](auto full, int vb) {
+        constexpr bool kFull = decltype(full)::value;
+        int bin[U];
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (bin[u] >= 0) vote(bin[u]);
+    };
+    int vb = p.nviews;
+    for (; vb >= U; vb -= U) chunk(std::true_type{}, vb);
+    if (vb > 0) chunk(std::false_type{}, vb);
+    // the views E-1 .. 0 from the record, kReplay bytes of it in flight per lane
+    constexpr int kReplay = 16;
+    const int lane = threadIdx.x & 63;
+    const uint8_t* __restrict__ r = rec + (i - lane) * E + lane;
+    for (int v0 = E; v0 > 0; v0 -= kReplay) {
+        unsigned b[kReplay];
+#pragma unroll
+        for (int j = 0; j < kReplay; ++j) {
+            const int v = v0 - 1 - j;
+            const unsigned got = r[max(v, 0) * 64];  // unconditional load + select
+            b[j] = v >= 0 ? got : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < kReplay; ++j)
+            if (b[j]) vote((int)b[j] - 1);
+    }
+    if (valid) {
+        const long long o = p.perm ? (long long)p.perm[i] : i;
+        labels[o] = best - 1 + (best < 0);  // bin b -> label b-1; no vote -> -1 (dls.py:306)
+    }
+}
+
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {  // v_pk_max_u16
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
@@ -1949,6 +2041,7 @@ static constexpr int kEarlyPitch = 256;                    // views per block of
 static constexpr long long kEarlyMinGaussians = 1 << 18;   // below this the vote is too short to be worth a second stream
 static constexpr int kEarlyMinViews = 32;
 static constexpr double kEarlyUsPerGaussianView = 4.4e-6;  // early stage on MI355X: 1.6 ms for 3 M Gaussians x 140 views, + 15 %
+static constexpr double kRecordUsPerGaussianView = 1.7e-6;  // record-only stage (early_replay): 0.62 ms for the same, + 15 %
 static constexpr size_t kEarlySlack = 64 * 260;           // the last stage reads whole groups of four rows, up to row 4 * kRegRows - 1, whatever the bin count
 static constexpr size_t kEarlyCullDoubles = (size_t)kCullStride * kCullPlanes * kEarlyPitch;
 
@@ -2035,7 +2128,7 @@ static int early_vote_stage(Ctx* c) {
         if (nv == 1) c->early_t0 = now;
         if (nv < std::max(8, c->total_views / 4)) return GSX_OK;
         const double t_map = std::chrono::duration<double, std::micro>(now - c->early_t0).count() / (double)(nv - 1);
-        const double t_view = kEarlyUsPerGaussianView * (double)c->n;
+        const double t_view = (c->opt_early_replay ? kRecordUsPerGaussianView : kEarlyUsPerGaussianView) * (double)c->n;
         const int lo = (c->total_views + 1) / 2, hi = (int)(((long long)c->total_views * 880) / 1000);
         const int want = std::min(std::max((int)std::ceil(c->total_views * t_map / (t_map + t_view)), lo), std::max(lo, hi));
         if (nv < want) return GSX_OK;
@@ -2046,14 +2139,33 @@ static int early_vote_stage(Ctx* c) {
     if (rc) return rc;
     if ((rc = early_streams(c))) return rc;
     const size_t plane = (size_t)c->bins * (size_t)c->n_pad;
-    GSX_HIP(c, c->ecnt.ensure(plane + kEarlySlack));
-    GSX_HIP(c, c->efv.ensure(plane + kEarlySlack));
+    if (!c->opt_early_replay) {
+        GSX_HIP(c, c->ecnt.ensure(plane + kEarlySlack));
+        GSX_HIP(c, c->efv.ensure(plane + kEarlySlack));
+    }
     GSX_HIP(c, c->erec.ensure((size_t)c->n_pad * (size_t)at));
     if ((rc = ensure_tally(c))) return rc;
     GSX_HIP(c, hipEventRecord(c->early_maps_ev, c->stream));
     GSX_HIP(c, hipStreamWaitEvent(c->stream2, c->early_maps_ev, 0));
     int dm = kDivFlat;
     if ((rc = early_upload(c, 0, at, 0, 2, c->stream2, &dm))) return rc;
+    if (c->opt_early_replay) {  // record only: the last stage replays it
+        FusedParams p = early_params(c, 0, at, 0, 1);
+        auto kr = dm == kDivFlatCoarse ? vote_record_kernel<kUnroll, kDivFlatCoarse>
+                  : dm == kDivFlatSimple ? vote_record_kernel<kUnroll, kDivFlatSimple>
+                                         : vote_record_kernel<kUnroll, kDivFlat>;
+        {
+            ProfScope ps(c, "vote_early_record", c->stream2);
+            hipLaunchKernelGGL(kr, dim3(grid_for(c->n)), dim3(kBlock), 0, c->stream2, p, p.views, c->erec.as<uint8_t>());
+            GSX_HIP(c, hipGetLastError());
+        }
+        GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+        c->early_done = at;
+        c->early_state = 1;
+        c->early_replayed = true;
+        return GSX_OK;
+    }
+    c->early_replayed = false;
     FusedParams p = early_params(c, 0, at, 0, 2);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
     auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
@@ -2115,6 +2227,21 @@ static int early_vote_finish(Ctx* c) {
     int dm = kDivFlat;
     if ((rc = early_upload(c, c->early_done, nv, 1, 2, c->stream, &dm))) return rc;
     GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
+    if (c->early_replayed) {
+        FusedParams pr = early_params(c, c->early_done, nv, 1, 1);
+        const size_t ldsr = (size_t)kBlock * pr.stride_dw * 4;
+        auto kr = dm == kDivFlatCoarse ? vote_fused_replay_kernel<kUnroll, kDivFlatCoarse>
+                  : dm == kDivFlatSimple ? vote_fused_replay_kernel<kUnroll, kDivFlatSimple>
+                                         : vote_fused_replay_kernel<kUnroll, kDivFlat>;
+        if ((rc = set_lds(c, kr, ldsr))) return rc;
+        GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+        if ((c->opt_ablate >> 4) & 2) pr.nviews = 0;  // timing experiment (tools/early_probe.py)
+        ProfScope ps(c, "vote_fused_replay");
+        hipLaunchKernelGGL(kr, dim3(grid_for(c->n)), dim3(kBlock), ldsr, c->stream, pr, pr.views, c->erec.as<uint8_t>(), c->early_done,
+                           c->labels.as<int>());
+        GSX_HIP(c, hipGetLastError());
+        return GSX_OK;
+    }
     FusedParams p = early_params(c, c->early_done, nv, 1, 1);
     const size_t lds = (size_t)(kBlock / 64) * ((c->bins + 3) / 4) * 256;  // per wave: [bin][64] bytes, rows padded to a multiple of four
     constexpr int kRegRows = 38;  // bins <= 152 (the 150 ADE20K classes + unlabelled): the first-view rows wait in registers

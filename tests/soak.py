@@ -35,6 +35,7 @@ with gsx.Context(0) as c:
         opts["labels_u8"] = int(rng.random() < 0.8)
         opts["host_compact"] = int(rng.random() < 0.7)
         opts["early_vote"] = int(rng.choice([0, 2, 2]))
+        opts["early_replay"] = int(rng.integers(0, 2))
         opts["early_vote_at"] = int(rng.integers(0, 1001)) if rng.random() < 0.85 else 0
         for k, v in opts.items():
             c.set_option(k, v)

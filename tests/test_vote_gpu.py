@@ -201,8 +201,9 @@ def _kernel_launches(c, name):
     return c.profile_get(name)[0] if name in c.profile_names() else 0
 
 
+@pytest.mark.parametrize("replay", [0, 1], ids=["planes", "replay"])
 @pytest.mark.parametrize("case", golden_assign_cases(), ids=lambda c: c[0])
-def test_early_vote_matches_reference_golden(gsx, case):
+def test_early_vote_matches_reference_golden(gsx, case, replay):
     """The first views of a run voted on a second stream while the rest is handed over (option early_vote), the last stage
     on top of their planes: the reference's labels for every split point, incl. the ties fixture."""
     name, pos, cams, segs, sizes, labels = case
@@ -211,6 +212,8 @@ def test_early_vote_matches_reference_golden(gsx, case):
         pytest.skip("one view: nothing to split")
     with gsx.Context(0) as c:
         c.set_option("early_vote", 2)
+        c.set_option("early_replay", replay)   # 1: the early stage only records the votes, the last stage replays them
+        last, first = ("vote_fused_replay", "vote_early_record") if replay else ("vote_fused_final", "vote_early_planes")
         c.profile(True)
         finals = 0
         for permille in sorted({1, 250, 500, 750, (1000 * (V - 1)) // V}):
@@ -220,10 +223,10 @@ def test_early_vote_matches_reference_golden(gsx, case):
                 got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
                 assert np.array_equal(got, labels), (name, permille, wave_cull)
                 finals += max(1, -(-V * permille // 1000)) < V  # a stage that would take every view is not started
-                assert _kernel_launches(c, "vote_fused_final") == finals and _kernel_launches(c, "vote_early_planes") == finals
+                assert _kernel_launches(c, last) == finals and _kernel_launches(c, first) == finals
             c.vote_rewind()  # a rewound run is voted in one piece
             assert np.array_equal(c.vote_finalize(), labels)
-            assert _kernel_launches(c, "vote_fused_final") == finals
+            assert _kernel_launches(c, last) == finals
 
 
 def test_early_vote_on_a_large_scene(gsx):
@@ -989,6 +992,7 @@ def test_randomised_small_configurations(gsx):
             c.set_option("wave_cull", int(rng.integers(0, 2)))
             c.set_option("seg_coarse", int(rng.integers(0, 2)))
             c.set_option("early_vote", int(rng.choice([0, 2])))
+            c.set_option("early_replay", int(rng.integers(0, 2)))
             c.set_option("early_vote_at", int(rng.integers(1, 1001)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []

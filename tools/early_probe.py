@@ -43,7 +43,7 @@ def measure(tag):
     a = np.array(rows)
     med = np.median(a, axis=0)
     ks = []
-    for k in ("vote_fused_labels", "vote_early_planes", "vote_fused_final", "seg_expand"):
+    for k in ("vote_fused_labels", "vote_early_planes", "vote_fused_final", "vote_early_record", "vote_fused_replay", "seg_expand"):
         if k in ctx.profile_names():
             cnt, ms = ctx.profile_get(k)
             if cnt:
@@ -61,6 +61,15 @@ for at in (0, 700, 0):   # 0: split point from the hand-over rate
     got = measure(f"early at {at:4d}")
     print(f"    early views {ctx.vote_early_views()}", flush=True)
     assert np.array_equal(got, ref), at
+ctx.set_option("early_replay", 1)      # record + replay instead of planes + fold
+for at in (700, 800, 850, 880, 920):
+    ctx.set_option("early_vote_at", at)
+    got = measure(f"replay at {at:4d}")
+    assert np.array_equal(got, ref), at
+ctx.set_option("ablate", 32)
+measure("replay at  920, no views behind the early ones")
+ctx.set_option("ablate", 0)
+ctx.set_option("early_replay", 0)
 ctx.set_option("early_vote_at", 700)
 for ab in (32, 0):     # timing only, see vote.hip early_vote_finish
     ctx.set_option("ablate", ab)
