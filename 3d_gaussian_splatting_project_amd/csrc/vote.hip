@@ -2030,13 +2030,15 @@ static constexpr int kUnroll = 8;
 FusedParams fused_params(Ctx* c, int stride_bytes_per_bin);
 // A run is the hand-over of its maps (the host pass over them, ~37 us per 1080p map) followed by the vote over all of
 // them (~1.2 ms for 3 M Gaussians x 200 views) with the GPU idle during the first and the host during the second.
-// When `early_vote_at` permille of the announced views are staged, their vote starts on a second stream
-// (vote_fused_planes_kernel into ecnt / efv: counts and first-view codes per bin) while the host goes on packing; what
-// vote_finalize still has to do behind the last map is the walk over the remaining views plus one pass over the two
-// planes (vote_fused_final_kernel).  Same labels, bit for bit: the planes keep everything the tie rule needs.
-// Only where it pays and is simple: one rank holds all views of the run (<= 255), they arrive one by one through
-// gsx_vote_view, the branchless projection is on.  Anything else (rewind, flush, exchange protocols, a pool that had to
-// move) ignores the early planes and votes all views in one piece as before.
+// When enough of the announced views are staged (`early_vote_at` permille, or a split chosen from the hand-over rate), their
+// vote starts on a second stream (vote_fused_planes_kernel into ecnt / efv: counts and first-view codes per bin, plus the
+// record of every vote) while the host goes on packing; what vote_finalize still has to do behind the last map is the walk
+// over the remaining views plus one pass over the two planes (vote_fused_final_kernel).  Same labels, bit for bit: the
+// planes keep everything the tie rule needs.  (Option early_replay: record only + replay, see vote_record_kernel.)
+// More than 255 announced views: early_batch_stage starts the batches' count kernels one by one.
+// Only where it pays and is simple: one rank holds all views of the run, they arrive one by one through gsx_vote_view, the
+// branchless projection is on.  Anything else (rewind, flush, exchange protocols, a pool that had to move) ignores the
+// early results and votes all views in one piece as before.
 static constexpr int kEarlyPitch = 256;                    // views per block of culling planes (>= kMaxBatch)
 static constexpr long long kEarlyMinGaussians = 1 << 18;   // below this the vote is too short to be worth a second stream
 static constexpr int kEarlyMinViews = 32;
