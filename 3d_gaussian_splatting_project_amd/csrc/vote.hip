@@ -2058,6 +2058,23 @@ static bool early_possible(const Ctx* c) { return early_common(c) && c->total_vi
 // left behind the last map
 static bool early_batched_possible(const Ctx* c) { return early_common(c) && c->total_views > kMaxBatch && c->opt_batched_counts; }
 static int early_batch_stage(Ctx* c);
+// The early batches: a short LAST batch (its count kernel is what stays behind the last map) after balanced ones of <= 255
+// views.  Any cut of the view order into consecutive batches gives the same labels (the earliest batch wins a tie).
+static int early_batch_count(int total) {
+    const int tail = std::min(std::max(total / 16, 16), 64), body = total - tail;
+    return (body + kMaxBatch - 1) / kMaxBatch + 1;
+}
+static void early_batch_bounds(int total, int s, int& lo, int& hi) {
+    const int tail = std::min(std::max(total / 16, 16), 64), body = total - tail;
+    const int Sb = (body + kMaxBatch - 1) / kMaxBatch;
+    if (s >= Sb) {
+        lo = body;
+        hi = total;
+    } else {
+        lo = (int)((long long)body * s / Sb);
+        hi = (int)((long long)body * (s + 1) / Sb);
+    }
+}
 
 // Descriptors and culling planes of the views [lo, hi) -> e_views[lo..hi), culling block `block` of e_cull, on stream st.
 // dm: the projection variant these views allow.
@@ -2189,10 +2206,11 @@ static int early_vote_stage(Ctx* c) {
 
 static int early_batch_stage(Ctx* c) {
     const int nv = (int)c->views.size();
-    const int S = (c->total_views + kMaxBatch - 1) / kMaxBatch;
+    const int S = early_batch_count(c->total_views);
     const int s = c->early_batches;
     if (s >= S - 1) return GSX_OK;  // the last batch ends with the last view: vote_finalize launches it
-    const int lo = (int)((long long)c->total_views * s / S), hi = (int)((long long)c->total_views * (s + 1) / S);
+    int lo, hi;
+    early_batch_bounds(c->total_views, s, lo, hi);
     if (nv != hi) return GSX_OK;
     int rc = vote_flush_pending(c);
     if (rc) return rc;
@@ -2500,7 +2518,11 @@ static int labels_one_batch(Ctx* c, const VoteRange& r, const uint32_t* perm, in
 // Leaves the range's labels in Morton order at c->keys[0 .. r.n).
 static int labels_batched(Ctx* c, const VoteRange& r) {
     const int nv = (int)c->views.size();
-    const int S = (nv + kMaxBatch - 1) / kMaxBatch;
+    // batches whose count kernels already ran on the second stream while the run's later maps were handed over (early_batch_stage:
+    // same batches - the run brought exactly the announced views -, same planes, the whole scene)
+    const bool early = c->early_batches > 0 && c->early_state == 0 && early_batched_possible(c) && nv == c->total_views && r.i0 == 0 &&
+                       r.n == c->n;
+    const int S = early ? early_batch_count(nv) : (nv + kMaxBatch - 1) / kMaxBatch;
     const long long npad = (r.n + 255) / 256 * 256;
     const size_t plane = (size_t)c->bins * (size_t)npad;
     GSX_HIP(c, c->bcnt.ensure(plane * S));
@@ -2517,17 +2539,14 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
     const size_t lds = (size_t)kBlock * base.stride_dw * 4;
     int rc = set_lds(c, k, lds);
     if (rc) return rc;
-    auto batch = [&](int s, FusedParams& p) {  // views [lo, hi) of batch s, sizes differ by at most one
-        const int lo = (int)((long long)nv * s / S), hi = (int)((long long)nv * (s + 1) / S);
+    auto batch = [&](int s, FusedParams& p) {  // views [lo, hi) of batch s: balanced (sizes differ by at most one), or the early cut
+        int lo = (int)((long long)nv * s / S), hi = (int)((long long)nv * (s + 1) / S);
+        if (early) early_batch_bounds(nv, s, lo, hi);
         p = base;
         p.views = base.views + lo;
         p.nviews = hi - lo;
         if (p.cull) p.cull = base.cull + lo;
     };
-    // batches whose count kernels already ran on the second stream while the run's later maps were handed over (early_batch_stage:
-    // same batches - the run brought exactly the announced views -, same planes, the whole scene)
-    const bool early = c->early_batches > 0 && c->early_state == 0 && early_batched_possible(c) && nv == c->total_views && r.i0 == 0 &&
-                       r.n == c->n;
     const int s0 = early ? c->early_batches : 0;
     if (early) GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
     for (int s = s0; s < S; ++s) {

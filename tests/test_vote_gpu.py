@@ -453,14 +453,18 @@ def test_early_count_batches_with_more_than_255_views(gsx):
             c.vote_begin(6, 0, V)
             for v in range(m):
                 c.vote_view(cams[v], segs[v], sizes[v])
-            S = -(-V // 255)
-            started = 0 if opts.get("flat_project") == 0 else sum(1 for b in range(S - 1) if V * (b + 1) // S <= m)
-            assert c.vote_early_views() == (V * started // S if started else 0)
+            # the early cut: balanced batches of <= 255 views and a short last one (16 .. 64 views)
+            tail = min(max(V // 16, 16), 64)
+            Sb = -(-(V - tail) // 255)
+            ends = [(V - tail) * (b + 1) // Sb for b in range(Sb)]
+            started = 0 if opts.get("flat_project") == 0 else sum(1 for e in ends if e <= m)
+            assert c.vote_early_views() == (ends[started - 1] if started else 0)
             got = c.vote_finalize()
             assert np.array_equal(got, want), (V, stop, opts)
             assert _kernel_launches(c, "vote_early_counts") == started
-            used = started if m == V else 0      # early planes are only used when the run brought the announced views
-            assert _kernel_launches(c, "vote_fused_counts") == -(-m // 255) - used, (V, stop, opts)
+            # early planes are only used when the run brought the announced views; else balanced batches of the views that came
+            left = (Sb + 1 - started) if (m == V and started) else -(-m // 255)
+            assert _kernel_launches(c, "vote_fused_counts") == left, (V, stop, opts)
             c.vote_rewind()
             assert np.array_equal(c.vote_finalize(), want), (V, stop, opts, "one piece")
 
