@@ -131,10 +131,12 @@ def render_leg(pkg, ctx, args, W, H):
         for cam in cams:
             ctx.render_view(cam, W, H, to_host=False)
     dt_one = (time.perf_counter() - t0) / reps
-    reps_many = 2 * reps                                   # one call: the streams' host threads start and end once
+    reps_many = 2 * reps                                   # per call: the streams' host threads start and end once
+    ctx.render_views(cams * reps_many, W, H, to_host=False)   # warm-up of the same shape
     t0 = time.perf_counter()
-    ctx.render_views(cams * reps_many, W, H, to_host=False)
-    dt = (time.perf_counter() - t0) / reps_many
+    for _ in range(2):
+        ctx.render_views(cams * reps_many, W, H, to_host=False)
+    dt = (time.perf_counter() - t0) / (2 * reps_many)
     ctx.profile(True)
     pairs = consumed = 0
     for cam in cams:
