@@ -121,6 +121,7 @@ _SIGS = {
     "gsx_kmeans": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
                              C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "gsx_vote_culled": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int32]),
+    "gsx_debug_filter_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_debug_cull_planes": (C.c_int, [C.POINTER(Camera), C.c_void_p]),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -195,6 +195,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "seg_coarse") c->opt_seg_coarse = value != 0;
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
+    else if (k == "filter_project") c->opt_filter_project = value != 0;
     else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;
@@ -208,7 +209,9 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     }
     else if (k == "host_prefetch") gsx::set_host_prefetch((int)value);
     else if (k == "host_prefetch_burst") gsx::set_host_prefetch_burst(value != 0);
+#ifdef GSX_EXPERIMENTS
     else if (k == "ablate") c->opt_ablate = (int)value;
+#endif
     else if (k == "host_threads") {
         if (value < 0 || value > 256) return gsx::fail(c, GSX_E_INVALID, "set_option: host_threads must be in [0,256]");
         if ((int)value != c->opt_host_threads) {
@@ -367,7 +370,7 @@ int gsx_debug_host_pack_compact(const void* seg, int32_t seg_dtype, int32_t w, i
 int gsx_debug_host_pack(const void* seg, int32_t seg_dtype, int32_t w, int32_t h, int32_t n_classes, int32_t tiled,
                         int32_t coarse, int32_t threads, uint8_t* out, int64_t out_cap, int64_t* bytes, int64_t* coarse_off,
                         int32_t* bad) {
-    return gsx::debug_host_pack(seg, seg_dtype, w, h, n_classes, tiled, coarse, threads, out, out_cap, bytes, coarse_off, bad);
+    return gsx::guard(nullptr, __func__, [&] { return gsx::debug_host_pack(seg, seg_dtype, w, h, n_classes, tiled, coarse, threads, out, out_cap, bytes, coarse_off, bad); });
 }
 int32_t gsx_vote_num_views(const gsx_ctx* ctx) {
     const Ctx* c = reinterpret_cast<const Ctx*>(ctx);
@@ -375,7 +378,7 @@ int32_t gsx_vote_num_views(const gsx_ctx* ctx) {
 }
 int gsx_vote_rewind(gsx_ctx* ctx) {
     CTX_OR_FAIL(ctx);
-    return gsx::vote_rewind(c);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_rewind(c); });
 }
 int gsx_vote_finalize(gsx_ctx* ctx, int32_t* labels_out) {
     CTX_OR_FAIL(ctx);
@@ -482,7 +485,12 @@ int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* sla
 }
 int gsx_host_threads(gsx_ctx* ctx) {
     Ctx* c = reinterpret_cast<Ctx*>(ctx);
-    return c ? gsx::host_threads(c) : 0;
+    if (!c) return 0;
+    try {
+        return gsx::host_threads(c);  // may create the worker pool
+    } catch (...) {
+        return 1;  // no pool: maps are packed on the calling thread
+    }
 }
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
@@ -546,6 +554,12 @@ int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset) {
     CTX_OR_FAIL(ctx);
     if (!wave_views) return gsx::fail(c, GSX_E_INVALID, "vote_culled: NULL argument");
     return gsx::guard(c, __func__, [&] { return gsx::vote_culled(c, wave_views, reset != 0); });
+}
+
+int gsx_debug_filter_check(gsx_ctx* ctx, double* out) {
+    CTX_OR_FAIL(ctx);
+    if (!out) return gsx::fail(c, GSX_E_INVALID, "debug_filter_check: NULL argument");
+    return gsx::guard(c, __func__, [&] { return gsx::filter_check(c, out); });
 }
 
 int gsx_debug_cull_planes(const gsx_camera* cam, double* out) {

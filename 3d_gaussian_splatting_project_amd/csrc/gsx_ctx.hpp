@@ -94,7 +94,7 @@ struct alignas(64) ViewDesc {
     int cam_w, cam_h;   // camera width / height as integers (visibility test of the certified path)
     int coarse_row_bytes;   // bytes per strip of 16 coarse cells (0: this view has no coarse level)
     unsigned coarse_delta;  // byte offset of the coarse level from the map's own start
-    int pad_[2];
+    float hw32, hh32;       // half_w, half_h as floats (exact: the frame is <= 65535 pixels a side): the fp32 filter of the projection
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
 };
@@ -173,7 +173,11 @@ struct Ctx {
     Workers* workers = nullptr;
     int opt_host_threads = 0;  // 0: default_host_threads()
     int opt_host_compact = 1;  // host maps cross PCIe in the compact form (coarse level + the mixed cells' blocks), expanded on the GPU
-    int opt_ablate = 0;        // timing experiments only (results invalid): 1 = host maps are packed but not copied, 2 = copied but not packed
+#ifdef GSX_EXPERIMENTS  // `make experiments` only (libgsx_experiments.so, used by tools/): timing-only switches, results invalid
+    int opt_ablate = 0;        // 1 = host maps are packed but not copied, 2 = copied but not packed; << 4: last-stage ablations (vote.hip)
+#else
+    static constexpr int opt_ablate = 0;  // the product library has no such option: every branch on it folds away
+#endif
     int opt_labels_u8 = 1;     // 1: the labels cross PCIe as one byte each (bin = label + 1) and are widened by the workers; 0: as int32
     int opt_host_pack = 1;     // 1: host maps are narrowed to u8 by the workers (2.2 MB/map over PCIe); 0: raw copy + GPU pack kernel (8.3 MB/map)
     DevBuf dstage[kPinSlots];  // host_pack = 0: device-side landing zone of the raw map of each ring slot
@@ -220,6 +224,7 @@ struct Ctx {
     bool labels_valid = false;
     // early vote (vote.hip: early_vote_stage): the views [0, early_done) are voted on a second stream while the host is
     // still handing over the rest of the run; vote_finalize then only walks the views behind them
+    int opt_filter_project = 1;  // fp32 filter in front of the two fp64 divisions of the projection (vote.hip: project_filtered); exact by construction
     int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
     int opt_early_at = 0;        // the stage starts when this many permille of the announced views are staged; 0: chosen from the run's own hand-over rate
     std::chrono::steady_clock::time_point early_t0;  // first gsx_vote_view of the run
@@ -229,6 +234,7 @@ struct Ctx {
     int early_done = 0;          // views [0, early_done) are in ecnt / efv (or, > 255 announced views, in the first early_batches planes of bcnt)
     int early_batches = 0;       // > 255 announced views: batches of labels_batched() whose count kernels already ran on stream2
     hipStream_t stream2 = nullptr;
+    bool early_inflight = false; // early_done_ev was recorded on stream2 and c->stream has not been ordered behind it yet (early_join)
     hipEvent_t early_maps_ev = nullptr, early_done_ev = nullptr, early_up_ev = nullptr;
     DevBuf ecnt, efv;            // u8 [wave][bin][64]: counts / first-view codes of the early views
     DevBuf erec;                 // u8 [wave][view][64]: bin + 1 voted by each Gaussian in each early view
@@ -316,6 +322,7 @@ int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint3
                          const unsigned long long* n_dev, int bits, int* result_in);
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
+int filter_check(Ctx* c, double* out);
 int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, const int64_t* init_index, int max_iter,
            double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out, int32_t* converged_out);
 void debug_cull_planes(const gsx_camera* cam, double* out);

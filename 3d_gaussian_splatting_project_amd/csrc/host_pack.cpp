@@ -203,8 +203,13 @@ static std::vector<cpu_set_t> l3_domains(int want_node) {
 }
 
 Workers::Workers(int threads, int numa_node) : impl_(new Impl), nthreads_(threads < 1 ? 1 : threads) {
-    impl_->nthreads = nthreads_;
-    impl_->slots = new Slot[(size_t)nthreads_];
+    Impl* const impl = impl_;  // the threads capture the Impl, not `this`: a Workers that fails to construct leaves nothing dangling
+    impl->nthreads = nthreads_;
+    impl->slots = new (std::nothrow) Slot[(size_t)nthreads_];
+    if (!impl->slots) {  // no room for the claim words: single-threaded packing
+        nthreads_ = impl->nthreads = 1;
+        impl->slots = new Slot[1];
+    }
     const std::vector<cpu_set_t> doms = nthreads_ > 1 ? l3_domains(numa_node) : std::vector<cpu_set_t>();
     // the caller itself sits in one of the domains (it is not moved); start dealing after it
     size_t first = 0;
@@ -212,10 +217,25 @@ Workers::Workers(int threads, int numa_node) : impl_(new Impl), nthreads_(thread
     for (size_t d = 0; d < doms.size(); ++d)
         if (cpu >= 0 && CPU_ISSET(cpu, &doms[d])) first = d;
     for (int i = 1; i < nthreads_; ++i) {
-        impl_->threads.emplace_back([this, i] { impl_->loop(i); });
+        try {
+            impl->threads.emplace_back([impl, i] { impl->loop(i); });
+        } catch (...) {
+            // thread or pid limit reached: stop and join the workers that did start and pack on the calling thread alone (their
+            // shares were cut for nthreads_ threads; a smaller pool would need them cut again)
+            {
+                std::lock_guard<std::mutex> lk(impl->m);
+                impl->stop.store(true);
+            }
+            impl->cv.notify_all();
+            for (auto& t : impl->threads) t.join();
+            impl->threads.clear();
+            impl->stop.store(false);
+            nthreads_ = impl->nthreads = 1;
+            break;
+        }
         if (doms.size() > 1) {
             const cpu_set_t& dom = doms[(first + (size_t)i) % doms.size()];
-            (void)pthread_setaffinity_np(impl_->threads.back().native_handle(), sizeof dom, &dom);
+            (void)pthread_setaffinity_np(impl->threads.back().native_handle(), sizeof dom, &dom);
         }
     }
 }

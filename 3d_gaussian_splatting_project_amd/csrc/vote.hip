@@ -45,6 +45,9 @@
 #ifndef GSX_ABLATE
 #define GSX_ABLATE 0  // product build; tools/ablate.sh builds timing-only variants (results invalid)
 #endif
+#if GSX_ABLATE && !defined(GSX_EXPERIMENTS)
+#error "GSX_ABLATE variants are experiments: build them with -DGSX_EXPERIMENTS (make experiments), never into libgsx.so"
+#endif
 
 #include "gsx_ctx.hpp"
 
@@ -52,6 +55,7 @@ namespace gsx {
 
 static constexpr int kBlock = 256;
 static constexpr int kMaxBatch = 255;  // views per fused launch: LDS counters are 8 bit
+int early_join(Ctx* c);
 
 // -------------------------------------------------------------------------------------------------
 // device: project_gaussian + seg-map addressing
@@ -65,6 +69,7 @@ struct ViewRegs {
     int seg_w, unit_scale, seg_row_bytes, cam_w, cam_h;
     int coarse_row_bytes;
     unsigned coarse_delta;
+    float hw32, hh32;
 };
 
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -101,7 +106,7 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
                       offsetof(ViewDesc, unit_scale) == 124 && offsetof(ViewDesc, half_w) == 128 &&
                       offsetof(ViewDesc, width) == 144 && offsetof(ViewDesc, seg_w) == 160 &&
                       offsetof(ViewDesc, cam_w) == 168 && offsetof(ViewDesc, coarse_row_bytes) == 176 &&
-                      offsetof(ViewDesc, coarse_delta) == 180 && sizeof(ViewDesc) % 64 == 0,
+                      offsetof(ViewDesc, coarse_delta) == 180 && offsetof(ViewDesc, hw32) == 184 && sizeof(ViewDesc) % 64 == 0,
                   "load_view reads the hot part of ViewDesc as 64 + 64 + 32 + 32 bytes");
     const char* q = reinterpret_cast<const char*>(vp);
     v16i a = *reinterpret_cast<const v16i*>(q);
@@ -125,6 +130,9 @@ __device__ __forceinline__ ViewRegs load_view(const ViewDesc* __restrict__ vp) {
     r.cam_h = d[3];
     r.coarse_row_bytes = d[4];
     r.coarse_delta = (unsigned)d[5];
+    const int hw_bits = d[6], hh_bits = d[7];  // (a bit_cast straight from a vector element reads element 0)
+    r.hw32 = __builtin_bit_cast(float, hw_bits);
+    r.hh32 = __builtin_bit_cast(float, hh_bits);
     return r;
 }
 
@@ -152,7 +160,9 @@ __device__ __forceinline__ double row_dot(const double* Rr, double v0, double v1
 // DIV == kDivFlatSimple: kDivFlat for a batch whose views ALL have unit scale and tiled maps (the host checks): the
 //   two wave-uniform tests per view disappear from the instruction stream.
 // DIV == kDivFlatCoarse: kDivFlatSimple for a batch whose maps all carry a coarse level (see gather_chunk).
-enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2, kDivFlatSimple = 3, kDivFlatCoarse = 4 };
+// DIV == kDivFiltCoarse: kDivFlatCoarse with the fp32 filter of project_filtered() in front of the two divisions.
+enum { kDivExact = 0, kDivCertified = 1, kDivFlat = 2, kDivFlatSimple = 3, kDivFlatCoarse = 4, kDivFiltCoarse = 5 };
+static constexpr int kDivModes = 6;
 
 // Two IEEE-754 divisions by the same denominator, bit-identical to `ax / b` and `ay / b`.
 // hipcc expands an fp64 division into div_scale(den), rcp, two Newton steps, div_scale(num), mul, fma, div_fmas,
@@ -231,6 +241,72 @@ __device__ __forceinline__ bool project(const ViewRegs& vd, double X, double Y, 
     return true;
 }
 
+// ---- filtered exact projection ------------------------------------------------------------------------------------------
+// project<kDivFlatSimple>() spends two thirds of its time on the two IEEE-754 divisions of dls.py:76-77 (v_div_scale, v_rcp_f64,
+// two Newton steps, v_div_fmas, v_div_fixup: ~43 ns of ~95 per wave and view, tools/valu_rate.hip) to obtain px, py to the last
+// bit - of which only floor() and the comparison with the frame are ever used.  Here the camera-space point (pc0, pc1, pc2) and
+// the products ax = fx * pc0, ay = fy * pc1 are the reference's own fp64 values as before, but the perspective division runs
+// in fp32: one v_rcp_f32 and two v_fma_f32 give px^, py^ with a PROVEN error bound E, and a lane whose px^ and py^ are both
+// farther than E from every integer has floor(px^) == floor(px), floor(py^) == floor(py) for certain - which decides the
+// visibility test (an integer frame: 0 <= px < W  <=>  0 <= floor(px) <= W - 1) and the pixel.  If any lane of the wave is
+// closer than that to an integer (or its depth lies outside [2^-40, 2^40)), the whole wave takes the exact divisions for
+// this view behind a wave-uniform branch: ~4 E of the lanes, i.e. one (wave, view) pair in ten at 1080p.  Bit-exact by
+// construction; the bound:
+//   u = 2^-24.  a^ = fl32(a) = a (1 + e1), z^ = fl32(pc2) = pc2 (1 + e2), |e1|, |e2| <= u (round to nearest; pc2 in
+//   [2^-40, 2^40) keeps z^ and r^ normal, and the 2^-126 absolute error of an a below the normal range is < 2^-86 after the
+//   multiplication by r^ <= 2^40); r^ = v_rcp_f32(z^) = (1 + e3) / z^ with |e3| <= 3 u (1 ulp by the ISA manual; the
+//   exhaustive check gsx_debug_filter_check() measures it on the device, and the GPU suite asserts <= 3 u);
+//   px^ = fl32(a^ r^ + hw) (fused, hw = W / 2 exact in fp32) = (a^ r^ + hw)(1 + e4), |e4| <= u.  With P = a / pc2 + hw:
+//   |px^ - P| <= |P - hw| ((1 + u)(1 + 3u) / (1 - u) - 1) + u |px^| / (1 - u) <= 5.01 u |P - hw| + 1.01 u |px^|.
+//   The reference's px = fl64(fl64(a / pc2) + hw) differs from P by <= 2^-52 (|P| + hw).
+//   Inside or within one pixel of the frame, |P - hw| <= W / 2 + 1 and |px^| <= W + 1:  |px^ - px| < 3.6 W u.
+//   E = 4 D u (kFilterK; D = the larger side of the largest frame of the batch, at least 64) leaves 10 % - 0.4 D u >= 2^-20 -
+//   for the terms dropped above (a few u) and for the rounding of fract() on (-1, 0) and of `fract - 0.5` (<= 2^-25 each).
+//   Outside that band no bound is needed: a lane is declared invisible only when floor(px^) lies outside [0, W - 1] while
+//   px^ is at least E away from the integers, and then P is on the same side of the frame (for px^ >= W + 1 or px^ <= -1
+//   the relative error 6.02 u cannot move P across the frame edge; between, the bound above applies); infinities saturate
+//   the conversion and fail the range test, NaNs fail the comparison with E and send the wave to the exact path.
+static constexpr double kFilterK = 4.0;
+__device__ __forceinline__ int cvt_floor_i32(float v) {
+    int k;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(k) : "v"(v));  // floor + saturating conversion in one instruction (NaN -> 0)
+    return k;
+}
+
+// filt_h = 0.5 - E.  Returns what project<kDivFlatSimple>() returns, bit for bit.
+__device__ __forceinline__ bool project_filtered(const ViewRegs& vd, float filt_h, double X, double Y, double Z, int& xi, int& yi) {
+    const double pc2 = row_dot(vd.R + 6, X, Y, Z) + vd.t[2];
+    const bool pos = pc2 > 0.0;  // dls.py:72
+    if (__builtin_amdgcn_ballot_w64(pos) == 0) return false;
+    const double q0 = row_dot(vd.R + 0, X, Y, Z) + vd.t[0];
+    const double q1 = row_dot(vd.R + 3, X, Y, Z) + vd.t[1];
+    const double ax = vd.fx * q0, ay = vd.fy * q1;
+    {
+        const float zf = (float)pc2, axf = (float)ax, ayf = (float)ay;
+        const float r = __builtin_amdgcn_rcpf(zf);
+        const float pxf = __builtin_fmaf(axf, r, vd.hw32), pyf = __builtin_fmaf(ayf, r, vd.hh32);
+        const float dx = __builtin_amdgcn_fractf(pxf) - 0.5f, dy = __builtin_amdgcn_fractf(pyf) - 0.5f;
+        // 2^-40 <= pc2 < 2^40, on the high word (a negative, zero, infinite or NaN depth fails)
+        const bool zrange = (unsigned)(__double2hiint(pc2) - 0x3D700000) < (unsigned)(0x42700000 - 0x3D700000);
+        const bool cert = zrange & (__builtin_fabsf(dx) <= filt_h) & (__builtin_fabsf(dy) <= filt_h);  // false for NaN
+        const int kx = cvt_floor_i32(pxf), ky = cvt_floor_i32(pyf);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(pos & !cert) == 0, 1)) {
+            xi = kx;
+            yi = ky;
+            return cert & ((unsigned)kx < (unsigned)vd.cam_w) & ((unsigned)ky < (unsigned)vd.cam_h);
+        }
+    }
+    // some lane is too close to a pixel boundary: the exact divisions for the whole wave (dls.py:76-81)
+    double qx, qy;
+    div2_shared(ax, ay, pc2, qx, qy);
+    const double fpx = qx + vd.half_w, fpy = qy + vd.half_h;
+    const bool vis = pos & (0.0 <= fpx) & (fpx < vd.width) & (0.0 <= fpy) & (fpy < vd.height);
+    if (!vis) return false;
+    xi = (int)fpx;
+    yi = (int)fpy;
+    return true;
+}
+
 // The vote of one Gaussian in one view: the map byte (bin = label + 1) under its projection, or -1 where the
 // reference skips the pair (dls.py:278-279).  All in-map offsets are 32-bit (maps are <= 65535 x 65535, checked in
 // vote_view), added to the view's wave-uniform base pointer: the gather is `global_load_ubyte v, v_off, s[base]`.
@@ -289,12 +365,14 @@ __global__ __launch_bounds__(kBlock) void project_kernel(const float* __restrict
                                                          const float* __restrict__ z, long long n,
                                                          const ViewDesc* __restrict__ vd,
                                                          const uint32_t* __restrict__ perm, int* __restrict__ ox,
-                                                         int* __restrict__ oy) {
+                                                         int* __restrict__ oy, float filt_h) {
     const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    const bool valid = i < n;  // (no early return: the flat forms ballot over the whole wave)
     int xi, yi;
     const ViewRegs vr = load_view(vd);
-    const bool vis = project<DIV>(vr, (double)x[i], (double)y[i], (double)z[i], xi, yi);
+    const double X = valid ? (double)x[i] : __builtin_nan(""), Y = valid ? (double)y[i] : 0.0, Z = valid ? (double)z[i] : 0.0;
+    const bool vis = DIV == kDivFiltCoarse ? project_filtered(vr, filt_h, X, Y, Z, xi, yi) : project<DIV>(vr, X, Y, Z, xi, yi);
+    if (!valid) return;
     const long long o = perm ? (long long)perm[i] : i;  // back to the caller's order
     ox[o] = vis ? xi : -1;
     oy[o] = vis ? yi : -1;
@@ -485,6 +563,7 @@ struct FusedParams {
     const double* cull;    // culling planes of the batch's views, [25][cull_pitch] (nullptr: no culling)
     int cull_pitch;
     unsigned long long* cull_tally;  // [0] += (wave, view) pairs skipped
+    float filt_h;                    // kDivFiltCoarse: 0.5 - E of project_filtered() for the largest frame among the staged views
 };
 
 // ---- wave-level view culling ------------------------------------------------------------------------------------
@@ -569,8 +648,8 @@ typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
 
 template <int U, int DIV, bool FULL>
 __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views, const uint8_t* __restrict__ pool, int vb,
-                                             double X, double Y, double Z, unsigned culled, int (&bin)[U]) {
-    if (DIV == kDivFlatCoarse) {
+                                             double X, double Y, double Z, unsigned culled, int (&bin)[U], float filt_h) {
+    if (DIV == kDivFlatCoarse || DIV == kDivFiltCoarse) {
         // Two-level lookup.  Every map carries a 4x4-coarsened copy whose cell holds the label shared by its 16
         // pixels, or 255 where they differ.  The patch of pixels a wave gathers is ~30 px wide and costs ~16 L2
         // requests per view in the full-resolution map (one per 128-B line = 16x8 pixels; the L2 request rate, not
@@ -585,7 +664,7 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
             if (((culled >> u) & 1u) || !(FULL || v >= 0)) continue;  // wave-uniform
             const ViewRegs vd = load_view(views + v);
             int xi, yi;
-            if (project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
+            if (DIV == kDivFiltCoarse ? project_filtered(vd, filt_h, X, Y, Z, xi, yi) : project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
                 pixel[u] = (unsigned)xi | ((unsigned)yi << 16);
                 const unsigned cx = (unsigned)xi >> 2, cy = (unsigned)yi >> 2;
                 const unsigned coff = __umul24(cx >> 4, (unsigned)vd.coarse_row_bytes) + (cx & 15u) + (cy << 4);
@@ -645,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
 #if GSX_ABLATE & 1  // timing experiment only: no LDS histogram, the bins are just consumed
 #pragma unroll
         for (int u = 0; u < U; ++u) best += bin[u];
@@ -730,7 +809,7 @@ __global__ __launch_bounds__(kBlock) void vote_record_kernel(FusedParams p, cons
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (kFull || vb - 1 - u >= 0) r[(vb - 1 - u) * 64] = (uint8_t)(bin[u] + 1);
@@ -769,7 +848,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_replay_kernel(FusedParams p
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (bin[u] >= 0) vote(bin[u]);
@@ -809,7 +888,12 @@ __global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams
                                                                      const uint8_t* __restrict__ cntA,
                                                                      const uint8_t* __restrict__ fvA,
                                                                      const uint8_t* __restrict__ recA, int E,
-                                                                     int* __restrict__ labels, int ablate) {
+                                                                     int* __restrict__ labels, int ablate_arg) {
+#ifdef GSX_EXPERIMENTS
+    const int ablate = ablate_arg;  // timing experiments (tools/early_probe.py), results invalid
+#else
+    constexpr int ablate = 0;       // product build: every branch on it folds away
+#endif
     extern __shared__ uint32_t lds[];
     const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     const bool valid = i < p.n;
@@ -870,7 +954,7 @@ __global__ __launch_bounds__(kBlock, 4) void vote_fused_final_kernel(FusedParams
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (bin[u] >= 0) {
@@ -957,7 +1041,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_counts_kernel(FusedParams p
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (bin[u] >= 0) h[bin[u]] = (uint8_t)(h[bin[u]] + 1);
@@ -1139,7 +1223,7 @@ __global__ __launch_bounds__(kBlock) void vote_fused_planes_kernel(FusedParams p
     auto chunk = [&](auto full, int vb) {
         constexpr bool kFull = decltype(full)::value;
         int bin[U];
-        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin);
+        gather_chunk<U, DIV, kFull>(views, pool, vb, X, Y, Z, cull_bits<U>(cmask, p.nviews - vb), bin, p.filt_h);
         if (rec) {  // early vote: the record of every vote, [wave][view][64 lanes] bytes (bin + 1, 0 = none) - the last stage
                     // looks the winner's bin up by the view of its first vote
             uint8_t* r = rec + (i - (threadIdx.x & 63)) * p.nviews + (threadIdx.x & 63);
@@ -1306,6 +1390,8 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.height = (double)cam->height;
     vd.cam_w = cam->width;
     vd.cam_h = cam->height;
+    vd.hw32 = (float)vd.half_w;  // exact for frames up to 2^24 pixels a side
+    vd.hh32 = (float)vd.half_h;
     vd.wscale = (double)seg_w / (double)img_w;
     vd.hscale = (double)seg_h / (double)img_h;
     vd.seg_w = seg_w;
@@ -1318,7 +1404,13 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
 static inline int div_mode(const Ctx* c) {
     if (!c->opt_flat_project) return c->opt_fast_div ? kDivCertified : kDivExact;
     if (!c->views_simple) return kDivFlat;
-    return c->views_coarse && c->opt_seg_coarse ? kDivFlatCoarse : kDivFlatSimple;
+    return c->views_coarse && c->opt_seg_coarse ? (c->opt_filter_project ? kDivFiltCoarse : kDivFlatCoarse) : kDivFlatSimple;
+}
+// 0.5 - E of project_filtered() for the staged views (E grows with the frame: the largest one decides)
+static float filter_half_width(const Ctx* c) {
+    int dim = 64;
+    for (const ViewDesc& v : c->views) dim = std::max(dim, std::max(v.cam_w, v.cam_h));
+    return (float)(0.5 - kFilterK * (double)dim * 5.9604644775390625e-08);
 }
 static inline unsigned grid_for(long long n) { return (unsigned)((n + kBlock - 1) / kBlock); }
 
@@ -1336,15 +1428,21 @@ int project_all(Ctx* c, const gsx_camera* cam, const float* dx, const float* dy,
     hipError_t e = hipMemcpyAsync(dvd.p, &vd, sizeof vd, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         ProfScope ps(c, "project");
-        if (c->opt_flat_project)
+        // the filtered form is the vote kernels' (kDivFiltCoarse): frames up to 65535 pixels a side (hw32 exact, E < 1/64)
+        const int dim = std::max(cam->width, cam->height);
+        const float filt_h = (float)(0.5 - kFilterK * (double)std::max(dim, 64) * 5.9604644775390625e-08);
+        if (c->opt_flat_project && c->opt_filter_project && dim <= 65535)
+            hipLaunchKernelGGL(project_kernel<kDivFiltCoarse>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>(), filt_h);
+        else if (c->opt_flat_project)
             hipLaunchKernelGGL(project_kernel<kDivFlat>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
-                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>(), 0.f);
         else if (c->opt_fast_div)
             hipLaunchKernelGGL(project_kernel<kDivCertified>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
-                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>(), 0.f);
         else
             hipLaunchKernelGGL(project_kernel<kDivExact>, dim3(grid_for(n)), dim3(kBlock), 0, c->stream, dx, dy, dz, (long long)n,
-                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>());
+                               dvd.as<ViewDesc>(), perm, ox.as<int>(), oy.as<int>(), 0.f);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(x_host, ox.p, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream);
@@ -1385,6 +1483,10 @@ int vote_begin(Ctx* c, int n_classes, int first_view, int total_views) {
     c->planes_zero = false;
     c->planes_stale = false;
     c->labels_valid = false;
+    {
+        const int rcj = early_join(c);  // an abandoned run's early stage may still be running: this run reuses its buffers
+        if (rcj) return rcj;
+    }
     c->early_state = 0;
     c->early_done = 0;
     c->early_batches = 0;
@@ -1402,6 +1504,7 @@ static int pool_reserve(Ctx* c, size_t need) {
     }
     if (c->early_state == 1 || c->early_batches > 0) {  // the early stage reads the pool that is about to be freed
         GSX_HIP(c, hipStreamSynchronize(c->stream2));
+        c->early_inflight = false;
         c->early_state = -1;
         c->early_batches = 0;
     }
@@ -1474,9 +1577,14 @@ static void push_view(Ctx* c, const gsx_camera* cam, const MapLayout& L, size_t 
 static void launch_pack(Ctx* c, const PackArgs& a, int jobs, int seg_dtype, bool vec, long long cells);
 
 static Workers* host_workers(Ctx* c, const void* near = nullptr) {
-    if (!c->workers)
-        c->workers = new (std::nothrow) Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads(), numa_node_of(near));
-    return c->workers;  // nullptr (out of memory): single-threaded packing
+    if (!c->workers) {
+        try {
+            c->workers = new Workers(c->opt_host_threads > 0 ? c->opt_host_threads : default_host_threads(), numa_node_of(near));
+        } catch (...) {  // out of memory (a thread that cannot be started is handled inside: the pool then has one thread)
+            c->workers = nullptr;
+        }
+    }
+    return c->workers;  // nullptr: single-threaded packing on the calling thread
 }
 
 // Host map: the worker threads narrow it into the next slot of the pinned ring (u8 strips + coarse level, range
@@ -1905,6 +2013,50 @@ int vote_culled(Ctx* c, int64_t* out, bool reset) {
     return GSX_OK;
 }
 
+// ---- what project_filtered()'s proof assumes about the hardware, measured on the device -------------------------------
+// Exhaustive: v_rcp_f32 on EVERY float in [2^-41, 2^41] against the exact reciprocal (r * z in double is exact, so
+// |r z - 1| is the relative error of r); and the special cases of v_fract_f32 / v_cvt_flr_i32_f32 the filter meets.
+__global__ __launch_bounds__(kBlock) void filter_check_kernel(unsigned lo_bits, unsigned hi_bits, unsigned long long* worst) {
+    double m = 0.0;
+    for (unsigned long long b = (unsigned long long)lo_bits + (unsigned long long)blockIdx.x * kBlock + threadIdx.x; b <= hi_bits;
+         b += (unsigned long long)gridDim.x * kBlock) {
+        const float z = __builtin_bit_cast(float, (unsigned)b);
+        const float r = __builtin_amdgcn_rcpf(z);
+        m = fmax(m, fabs((double)r * (double)z - 1.0));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(worst, (unsigned long long)__double_as_longlong(m));  // non-negative doubles order as integers
+}
+__global__ void filter_special_kernel(double* out) {
+    const float inf = __builtin_inff(), nan = __builtin_nanf("");
+    volatile float in[8] = {inf, -inf, -1e-10f, nan, 1920.5f, -0.25f, 3.0e38f, -3.0e38f};
+    for (int k = 0; k < 8; ++k) {
+        const float v = in[k];
+        out[k] = (double)__builtin_amdgcn_fractf(v);
+        out[8 + k] = (double)cvt_floor_i32(v);
+    }
+}
+
+int filter_check(Ctx* c, double* out) {
+    GSX_HIP(c, hipSetDevice(c->device));
+    DevBuf buf;
+    GSX_HIP(c, buf.ensure(8 + 16 * sizeof(double)));
+    GSX_HIP(c, hipMemsetAsync(buf.p, 0, 8 + 16 * sizeof(double), c->stream));
+    const unsigned lo = 0x2B000000u /* 2^-41 */, hi = 0x54000000u /* 2^41 */;
+    hipLaunchKernelGGL(filter_check_kernel, dim3(4096), dim3(kBlock), 0, c->stream, lo, hi, buf.as<unsigned long long>());
+    hipLaunchKernelGGL(filter_special_kernel, dim3(1), dim3(1), 0, c->stream, reinterpret_cast<double*>(buf.as<char>() + 8));
+    GSX_HIP(c, hipGetLastError());
+    unsigned long long w = 0;
+    GSX_HIP(c, hipMemcpyAsync(&w, buf.p, 8, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(out + 1, buf.as<char>() + 8, 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    double m;
+    std::memcpy(&m, &w, 8);
+    out[0] = m / 5.9604644775390625e-08;  // in units of u = 2^-24
+    buf.release();
+    return GSX_OK;
+}
+
 void debug_cull_planes(const gsx_camera* cam, double* out) {
     ViewDesc vd;
     fill_view_desc(vd, cam, cam->width > 0 ? cam->width : 1, cam->height > 0 ? cam->height : 1, 1, 1);
@@ -2008,6 +2160,10 @@ int vote_rewind(Ctx* c) {
     c->labels_valid = false;
     c->early_state = -1;  // a rewound run is voted in one piece (its views are all there)
     c->early_batches = 0;
+    {
+        const int rcj = early_join(c);  // ... behind whatever the early stage is still doing to bcnt / ecnt / erec
+        if (rcj) return rcj;
+    }
     if (c->planes_valid) {
         c->planes_valid = false;
         c->planes_zero = false;
@@ -2104,7 +2260,7 @@ static int early_upload(Ctx* c, int lo, int hi, int block, int blocks, hipStream
         cull_planes(v, pl);
         for (int k = 0; k < kCullStride * kCullPlanes; ++k) planes[(size_t)k * kEarlyPitch + (i - lo)] = pl[k];
     }
-    *dm = !simple ? kDivFlat : (coarse && c->opt_seg_coarse ? kDivFlatCoarse : kDivFlatSimple);
+    *dm = !simple ? kDivFlat : (coarse && c->opt_seg_coarse ? (c->opt_filter_project ? kDivFiltCoarse : kDivFlatCoarse) : kDivFlatSimple);
     if (hi > lo) GSX_HIP(c, hipMemcpyAsync(c->e_views.as<ViewDesc>() + lo, hv, sizeof(ViewDesc) * (size_t)(hi - lo), hipMemcpyHostToDevice, st));
     GSX_HIP(c, hipMemcpyAsync(c->e_cull.as<double>() + (size_t)block * kEarlyCullDoubles, planes, cbytes, hipMemcpyHostToDevice, st));
     GSX_HIP(c, hipEventRecord(c->early_up_ev, st));
@@ -2118,6 +2274,16 @@ static FusedParams early_params(Ctx* c, int lo, int hi, int block, int stride_by
     p.cull = c->opt_wave_cull ? c->e_cull.as<double>() + (size_t)block * kEarlyCullDoubles : nullptr;
     p.cull_pitch = kEarlyPitch;
     return p;
+}
+
+// Orders c->stream behind whatever the second stream was last asked to do.  Needed wherever an early stage's buffers (ecnt,
+// efv, erec, bcnt) or the pool it reads are touched again: by the last stage that uses its result, and just as much by every
+// path that DROPS the result (fewer views than announced, rewind, a new run) and is about to overwrite those buffers.
+int early_join(Ctx* c) {
+    if (!c->early_inflight) return GSX_OK;
+    GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+    c->early_inflight = false;
+    return GSX_OK;
 }
 
 static int early_streams(Ctx* c) {
@@ -2170,7 +2336,8 @@ static int early_vote_stage(Ctx* c) {
     if ((rc = early_upload(c, 0, at, 0, 2, c->stream2, &dm))) return rc;
     if (c->opt_early_replay) {  // record only: the last stage replays it
         FusedParams p = early_params(c, 0, at, 0, 1);
-        auto kr = dm == kDivFlatCoarse ? vote_record_kernel<kUnroll, kDivFlatCoarse>
+        auto kr = dm == kDivFiltCoarse ? vote_record_kernel<kUnroll, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_record_kernel<kUnroll, kDivFlatCoarse>
                   : dm == kDivFlatSimple ? vote_record_kernel<kUnroll, kDivFlatSimple>
                                          : vote_record_kernel<kUnroll, kDivFlat>;
         {
@@ -2179,6 +2346,7 @@ static int early_vote_stage(Ctx* c) {
             GSX_HIP(c, hipGetLastError());
         }
         GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+        c->early_inflight = true;
         c->early_done = at;
         c->early_state = 1;
         c->early_replayed = true;
@@ -2187,7 +2355,8 @@ static int early_vote_stage(Ctx* c) {
     c->early_replayed = false;
     FusedParams p = early_params(c, 0, at, 0, 2);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-    auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
+    auto k = dm == kDivFiltCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
              : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
                                     : vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat>;
     if ((rc = set_lds(c, k, lds))) return rc;
@@ -2199,6 +2368,7 @@ static int early_vote_stage(Ctx* c) {
         GSX_HIP(c, hipGetLastError());
     }
     GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+    c->early_inflight = true;
     c->early_done = at;
     c->early_state = 1;
     return GSX_OK;
@@ -2224,7 +2394,8 @@ static int early_batch_stage(Ctx* c) {
     if ((rc = early_upload(c, lo, hi, s, S, c->stream2, &dm))) return rc;
     FusedParams p = early_params(c, lo, hi, s, 1);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
-    auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+    auto k = dm == kDivFiltCoarse ? vote_fused_counts_kernel<kUnroll, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
              : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
                                     : vote_fused_counts_kernel<kUnroll, kDivFlat>;
     if ((rc = set_lds(c, k, lds))) return rc;
@@ -2234,6 +2405,7 @@ static int early_batch_stage(Ctx* c) {
         GSX_HIP(c, hipGetLastError());
     }
     GSX_HIP(c, hipEventRecord(c->early_done_ev, c->stream2));
+    c->early_inflight = true;
     c->early_batches = s + 1;
     c->early_done = hi;
     return GSX_OK;
@@ -2250,11 +2422,12 @@ static int early_vote_finish(Ctx* c) {
     if (c->early_replayed) {
         FusedParams pr = early_params(c, c->early_done, nv, 1, 1);
         const size_t ldsr = (size_t)kBlock * pr.stride_dw * 4;
-        auto kr = dm == kDivFlatCoarse ? vote_fused_replay_kernel<kUnroll, kDivFlatCoarse>
+        auto kr = dm == kDivFiltCoarse ? vote_fused_replay_kernel<kUnroll, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_replay_kernel<kUnroll, kDivFlatCoarse>
                   : dm == kDivFlatSimple ? vote_fused_replay_kernel<kUnroll, kDivFlatSimple>
                                          : vote_fused_replay_kernel<kUnroll, kDivFlat>;
         if ((rc = set_lds(c, kr, ldsr))) return rc;
-        GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+        if ((rc = early_join(c))) return rc;
         if ((c->opt_ablate >> 4) & 2) pr.nviews = 0;  // timing experiment (tools/early_probe.py)
         ProfScope ps(c, "vote_fused_replay");
         hipLaunchKernelGGL(kr, dim3(grid_for(c->n)), dim3(kBlock), ldsr, c->stream, pr, pr.views, c->erec.as<uint8_t>(), c->early_done,
@@ -2266,11 +2439,12 @@ static int early_vote_finish(Ctx* c) {
     const size_t lds = (size_t)(kBlock / 64) * ((c->bins + 3) / 4) * 256;  // per wave: [bin][64] bytes, rows padded to a multiple of four
     constexpr int kRegRows = 38;  // bins <= 152 (the 150 ADE20K classes + unlabelled): the first-view rows wait in registers
     const bool regs = c->bins <= 4 * kRegRows;
-    auto k = dm == kDivFlatCoarse ? (regs ? vote_fused_final_kernel<kUnroll, kDivFlatCoarse, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlatCoarse, 0>)
+    auto k = dm == kDivFiltCoarse ? (regs ? vote_fused_final_kernel<kUnroll, kDivFiltCoarse, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFiltCoarse, 0>)
+                 : dm == kDivFlatCoarse ? (regs ? vote_fused_final_kernel<kUnroll, kDivFlatCoarse, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlatCoarse, 0>)
              : dm == kDivFlatSimple ? (regs ? vote_fused_final_kernel<kUnroll, kDivFlatSimple, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlatSimple, 0>)
                                     : (regs ? vote_fused_final_kernel<kUnroll, kDivFlat, kRegRows> : vote_fused_final_kernel<kUnroll, kDivFlat, 0>);
     if ((rc = set_lds(c, k, lds))) return rc;
-    GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
+    if ((rc = early_join(c))) return rc;
     // timing experiments (results invalid), option "ablate": 16 every wave reads the planes of wave 0; 32 no views behind the
     // early ones; 64 no pass over the first-view rows; 128 no look-up in the vote record; 256 labels stored in Morton order;
     // 512 no wave-level culling
@@ -2287,8 +2461,9 @@ static int early_vote_finish(Ctx* c) {
 int vote_flush(Ctx* c) {
     if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_flush before vote_begin");
     GSX_HIP(c, hipSetDevice(c->device));
-    int rc = sync_views(c);
+    int rc = early_join(c);
     if (rc) return rc;
+    if ((rc = sync_views(c))) return rc;
     rc = ensure_planes(c);
     if (rc) return rc;
     const int nv = (int)c->views.size();
@@ -2306,6 +2481,7 @@ int vote_flush(Ctx* c) {
     p.xcd_swizzle = c->opt_xcd_swizzle;
     p.perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
     p.stride_dw = odd_dwords(c->bins * 2);
+    p.filt_h = filter_half_width(c);
     const size_t lds = (size_t)kBlock * p.stride_dw * 4;
     while (c->n_flushed < nv) {
         const int batch = std::min(kMaxBatch, nv - c->n_flushed);
@@ -2319,7 +2495,8 @@ int vote_flush(Ctx* c) {
         ProfScope ps(c, "vote_fused_planes");
         if (c->wide) {
             const int dm = div_mode(c);
-            auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatCoarse>
+            auto k = dm == kDivFiltCoarse ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatCoarse>
                      : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlatSimple>
                      : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivFlat>
                      : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint16_t, kDivCertified>
@@ -2329,7 +2506,8 @@ int vote_flush(Ctx* c) {
                                c->fv.as<uint16_t>(), (long long)c->sn, view_base, fresh, 0, (uint8_t*)nullptr);
         } else {
             const int dm = div_mode(c);
-            auto k = dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
+            auto k = dm == kDivFiltCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatCoarse>
                      : dm == kDivFlatSimple ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlatSimple>
                      : dm == kDivFlat     ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivFlat>
                      : dm == kDivCertified ? vote_fused_planes_kernel<kUnroll, uint8_t, kDivCertified>
@@ -2496,8 +2674,9 @@ static int labels_one_batch(Ctx* c, const VoteRange& r, const uint32_t* perm, in
      {vote_fused_labels_kernel<U_, kDivCertified, false>, vote_fused_labels_kernel<U_, kDivCertified, true>}, \
      {vote_fused_labels_kernel<U_, kDivFlat, false>, vote_fused_labels_kernel<U_, kDivFlat, true>},           \
      {vote_fused_labels_kernel<U_, kDivFlatSimple, false>, vote_fused_labels_kernel<U_, kDivFlatSimple, true>}, \
-     {vote_fused_labels_kernel<U_, kDivFlatCoarse, false>, vote_fused_labels_kernel<U_, kDivFlatCoarse, true>}}
-    static const K table[3][5][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
+     {vote_fused_labels_kernel<U_, kDivFlatCoarse, false>, vote_fused_labels_kernel<U_, kDivFlatCoarse, true>},   \
+     {vote_fused_labels_kernel<U_, kDivFiltCoarse, false>, vote_fused_labels_kernel<U_, kDivFiltCoarse, true>}}
+    static const K table[3][kDivModes][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
 #undef GSX_ROW
     K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
     int rc = set_lds(c, k, lds);
@@ -2530,7 +2709,8 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
     GSX_HIP(c, c->bcodes.ensure(sizeof(uint16_t) * (size_t)npad * S));
     if (r.n <= 0) return GSX_OK;
     const int dm = div_mode(c);
-    auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+    auto k = dm == kDivFiltCoarse ? vote_fused_counts_kernel<kUnroll, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
              : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
              : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
              : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>
@@ -2548,7 +2728,6 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
         if (p.cull) p.cull = base.cull + lo;
     };
     const int s0 = early ? c->early_batches : 0;
-    if (early) GSX_HIP(c, hipStreamWaitEvent(c->stream, c->early_done_ev, 0));
     for (int s = s0; s < S; ++s) {
         FusedParams p;
         batch(s, p);
@@ -2580,8 +2759,11 @@ static int labels_batched(Ctx* c, const VoteRange& r) {
 // labels of a range of Gaussians over ALL staged views, whatever their number.  to_sorted: leave them in Morton order
 // at c->keys[0 .. r.n) (protocol v4); otherwise write c->labels in the caller's order (needs r = the whole scene).
 static int labels_for_range(Ctx* c, const VoteRange& r, bool to_sorted) {
-    int rc = sync_views(c);
+    // early or not: an early batch may still be writing its plane of bcnt on the second stream (a run that stopped short of the
+    // announced views, a rewind) - the buffers are (re)sized and the kernels launched behind it
+    int rc = early_join(c);
     if (rc) return rc;
+    if ((rc = sync_views(c))) return rc;
     GSX_HIP(c, c->keys.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
     GSX_HIP(c, c->labels.ensure(sizeof(int) * (size_t)(c->n_pad ? c->n_pad : 1)));
     const uint32_t* perm = c->sorted ? c->perm.as<uint32_t>() : nullptr;
@@ -2671,6 +2853,8 @@ int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* p
                             (unsigned long long)d.seg_off + (unsigned long long)part_offsets[r] + L.map_bytes <= (unsigned long long)pool_all_bytes;
             if (!ok) return fail(c, GSX_E_INVALID, "vote_import: descriptor %zu (part %d) is inconsistent with the gathered pool", k, r);
             d.seg_off += part_offsets[r];
+            d.hw32 = (float)d.half_w;  // (never trusted from the blob: the filter's proof needs exactly these)
+            d.hh32 = (float)d.half_h;
         }
     c->views.swap(all);
     c->views_dirty = true;
@@ -2713,6 +2897,7 @@ FusedParams fused_params(Ctx* c, int stride_bytes_per_bin) {
     p.cull = c->opt_wave_cull ? c->d_cull.as<double>() : nullptr;
     p.cull_pitch = c->cull_pitch;
     p.cull_tally = c->d_cull_tally.as<unsigned long long>();
+    p.filt_h = filter_half_width(c);
     return p;
 }
 
@@ -2730,7 +2915,8 @@ int vote_flush_counts(Ctx* c) {
         FusedParams p = fused_params(c, 1);
         const size_t lds = (size_t)kBlock * p.stride_dw * 4;
         const int dm = div_mode(c);
-        auto k = dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
+        auto k = dm == kDivFiltCoarse ? vote_fused_counts_kernel<kUnroll, kDivFiltCoarse>
+                 : dm == kDivFlatCoarse ? vote_fused_counts_kernel<kUnroll, kDivFlatCoarse>
                  : dm == kDivFlatSimple ? vote_fused_counts_kernel<kUnroll, kDivFlatSimple>
                  : dm == kDivFlat     ? vote_fused_counts_kernel<kUnroll, kDivFlat>
                  : dm == kDivCertified ? vote_fused_counts_kernel<kUnroll, kDivCertified>

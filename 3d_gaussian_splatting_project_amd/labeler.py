@@ -321,6 +321,12 @@ class Context:
         check(self._lib.gsx_vote_culled(self.h, C.byref(out), 1 if reset else 0), self.h)
         return int(out.value)
 
+    def debug_filter_check(self):
+        """gsx_debug_filter_check: [max relative error of v_rcp_f32 in units of 2^-24, fract x 8, floor-convert x 8]."""
+        out = np.zeros(17, np.float64)
+        check(self._lib.gsx_debug_filter_check(self.h, out.ctypes.data), self.h)
+        return out
+
     def debug_planes(self, bins):
         cnt = np.empty((bins, self.n), np.uint16)
         fv = np.empty((bins, self.n), np.uint16)

@@ -89,25 +89,7 @@ def make_segmaps(scene, torch, device, H, W, classes, seeds, cell):
     the CPU baseline consume."""
     if cell > 1:
         return [scene.make_segmap(H, W, classes, s, cell=cell) for s in seeds]
-    dev = torch.device("cuda", device)
-    ys = torch.arange(H, device=dev, dtype=torch.float64) + 0.5
-    xs = torch.arange(W, device=dev, dtype=torch.float64) + 0.5
-    out = []
-    rows = max(1, (1 << 18) // W)
-    for s in seeds:
-        rng = np.random.default_rng(s)
-        sites = rng.uniform(0.0, 1.0, size=(400, 2)) * np.array([W, H])
-        cls = rng.integers(-1, classes, size=400, dtype=np.int32)
-        sx = torch.from_numpy(sites[:, 0]).to(dev)
-        sy = torch.from_numpy(sites[:, 1]).to(dev)
-        tcls = torch.from_numpy(cls).to(dev)
-        seg = torch.empty((H, W), dtype=torch.int32, device=dev)
-        for y0 in range(0, H, rows):
-            y1 = min(H, y0 + rows)
-            d = (ys[y0:y1, None, None] - sy) ** 2 + (xs[None, :, None] - sx) ** 2
-            seg[y0:y1] = tcls[d.argmin(dim=2)]
-        out.append(seg.cpu().numpy())
-    return out
+    return [scene.make_segmap_gpu(torch, device, H, W, classes, s) for s in seeds]
 
 
 def render_leg(pkg, ctx, args, W, H):

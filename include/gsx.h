@@ -93,6 +93,11 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               pixel boundary (and any non-finite case) take the exact IEEE divisions.  Bit-identical
  *                               (tested on 7e7 pairs and at pixel boundaries) but measured 1 % SLOWER: 15 fewer fp64
  *                               instructions per visible pair, yet both axes are evaluated before the first early-out
+ *   "filter_project" (default 1) the two IEEE divisions of the projection are preceded by an fp32 filter (one v_rcp_f32, two
+ *                               v_fma_f32) with a proven error bound: a wave whose lanes are all farther than the bound from
+ *                               every pixel boundary takes floor() of the filter's result, any other wave the exact
+ *                               divisions for that view (about one wave and view in ten at 1080p).  Bit-identical by
+ *                               construction (csrc/vote.hip: project_filtered; gsx_debug_filter_check)
  *   "host_compact" (default 1)  host maps (gsx_vote_view) cross PCIe as their coarse level plus the 16-byte blocks of the
  *                               mixed 4x4 cells only, and a kernel behind the DMA rebuilds the pool form (the link, not
  *                               the host pass, is what the hand-over of 200 1080p maps waits for); 0 = the pool form
@@ -406,6 +411,11 @@ int gsx_debug_widen_labels(int32_t threads, const uint8_t* bins, int64_t n, int3
 /* statistics: (wave of 64 Gaussians, view) pairs the vote kernels skipped through the wave culling since the context
  * was created or since the last call with reset != 0 */
 int gsx_vote_culled(gsx_ctx* ctx, int64_t* wave_views, int32_t reset);
+/* test hook: what the fp32 filter in front of the projection's divisions (option "filter_project") assumes about the
+ * hardware, measured on the device.  out[17]: [0] = the largest relative error of v_rcp_f32 over EVERY float in
+ * [2^-41, 2^41], in units of 2^-24 (the filter's proof needs <= 3); [1..8] = v_fract_f32 and [9..16] =
+ * v_cvt_flr_i32_f32 of +inf, -inf, -1e-10, NaN, 1920.5, -0.25, 3e38, -3e38. */
+int gsx_debug_filter_check(gsx_ctx* ctx, double* out);
 /* test hook, host only (no context, no GPU): the five world-space culling planes the vote kernels use to skip whole
  * waves for a view (option "wave_cull"), as out[5][5] = unit normal A, offset B, margin slope M: a sphere (c, r) with
  * A.c + B > r + M (|c|_1 + r) holds no Gaussian that project_gaussian (deep_learning_segmentation.py:43-82) would

@@ -85,7 +85,7 @@ def test_results_do_not_depend_on_tuning_options(gsx):
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     for opts in ({"spatial_sort": 0, "xcd_swizzle": 0, "vote_unroll": 2, "seg_tiled": 0, "lds_batch": 0}, {"spatial_sort": 1, "xcd_swizzle": 0, "vote_unroll": 2},
                  {"spatial_sort": 0, "xcd_swizzle": 1, "vote_unroll": 8, "fast_div": 0}, {"spatial_sort": 1, "xcd_swizzle": 1, "vote_unroll": 4, "seg_tiled": 0},
-                 {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1},
+                 {"flat_project": 0}, {"flat_project": 0, "vote_unroll": 2, "spatial_sort": 0, "fast_div": 1}, {"filter_project": 0},
                  {"flat_project": 1, "vote_unroll": 4, "seg_tiled": 0, "xcd_swizzle": 0}, {"wave_cull": 0}, {"seg_coarse": 0}, {"labels_u8": 0}, {"host_compact": 0}, {"host_compact": 0, "host_threads": 3}, {"host_pack": 0}, {"host_pack": 0, "seg_tiled": 0, "host_threads": 2}, {"seg_coarse": 1, "wave_cull": 1, "vote_unroll": 2},
                  {"wave_cull": 1, "vote_unroll": 2, "spatial_sort": 0}, {"wave_cull": 1, "vote_unroll": 4, "flat_project": 0}):
         with gsx.Context(0) as c:
@@ -123,7 +123,7 @@ def test_project_extreme_exponents(gsx):
     # fraction 0.5) although the true quotient is 0.5 and 1.0
     cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-1e308, -1e308, -1e308]})
     cams.append({"fx": 0.5, "fy": 1.0, "width": 1921, "height": 1081, "rotation": R, "position": [-4e307, -8e307, -1.6e308]})
-    for shared in (("fast_div", 1), ("fast_div", 0), ("flat_project", 1)):
+    for shared in (("fast_div", 1), ("fast_div", 0), ("flat_project", 1), ("filter_project", 0)):
         with gsx.Context(0) as c:
             c.set_option(*shared)
             c.upload_positions(pos)
@@ -179,6 +179,74 @@ def test_certified_projection_equals_exact_divisions(gsx):
                 x, y = c.project_all(cam)
                 assert np.array_equal(x, ox) and np.array_equal(y, oy)
         assert (ox >= 0).sum() > 1000
+
+
+# ---- the fp32 filter in front of the projection's divisions (option filter_project, csrc/vote.hip: project_filtered) ----
+def test_filter_hardware_assumptions(ctx):
+    """What the filter's proof assumes about gfx950, measured on the device: v_rcp_f32 is within 3 u (u = 2^-24) of the exact
+    reciprocal for EVERY float in [2^-41, 2^41]; v_fract_f32 stays below 1 and never 'certifies' an infinity;
+    v_cvt_flr_i32_f32 is floor() with saturation."""
+    out = ctx.debug_filter_check()
+    assert 0.0 < out[0] <= 3.0, out[0]
+    fr, fl = out[1:9], out[9:17]          # +inf, -inf, -1e-10, NaN, 1920.5, -0.25, 3e38, -3e38
+    for k in (0, 1, 3):                    # infinities / NaN: NaN, or a value whose distance from 0.5 exceeds 0.5 - E
+        assert np.isnan(fr[k]) or fr[k] == 0.0, (k, fr[k])
+    assert 0.0 <= fr[2] < 1.0 and abs(fr[2] - 0.5) > 0.49
+    assert fr[4] == 0.5 and fr[5] == 0.75
+    assert fl[4] == 1920 and fl[5] == -1 and fl[2] == -1
+    assert fl[0] == 2 ** 31 - 1 and fl[6] == 2 ** 31 - 1 and fl[1] == -2 ** 31 and fl[7] == -2 ** 31
+
+
+from test_vote_gpu_points import boundary_points as _boundary_points
+
+
+def test_filtered_projection_at_pixel_boundaries(gsx):
+    """Points ON, a few float32 steps off, one filter bound (E = 4 W 2^-24) off and well off the pixel boundaries and the frame
+    edges: the filter must certify only what is certain and hand everything else to the exact divisions - same pixels as
+    the oracle, with and without it."""
+    u = 2.0 ** -24
+    for (fx, fy, W, H) in ((1728.0, 1728.0, 1920, 1080), (3172.5322265625, 3173.95, 3114, 2075), (1024.0, 512.0, 2048, 1024),
+                           (57.3, 91.7, 64, 48), (40000.1, 39999.9, 65535, 300)):
+        E = 4 * max(W, H, 64) * u
+        eps = [0.0, 1e-7, -1e-7, 3e-6, -3e-6, 0.5 * E, -0.5 * E, 0.9 * E, -0.9 * E, E, -E, 1.1 * E, -1.1 * E, 2 * E, -2 * E, 0.01, -0.01, 0.5]
+        pos = _boundary_points(fx, fy, W, H, (1.0, 3.7, 0.083, 41.0), eps)
+        cam = {"fx": fx, "fy": fy, "width": W, "height": H, "rotation": np.eye(3).tolist(), "position": [0, 0, 0]}
+        ox, oy = oracle.project_many(pos, cam)
+        assert (ox >= 0).mean() > 0.5
+        for filt in (1, 0):
+            with gsx.Context(0) as c:
+                c.set_option("filter_project", filt)
+                c.upload_positions(pos)
+                x, y = c.project_all(cam)
+                assert np.array_equal(x, ox) and np.array_equal(y, oy), (fx, W, filt, int((x != ox).sum()), int((y != oy).sum()))
+
+
+def test_filtered_vote_on_per_pixel_noise(gsx):
+    """The same boundary points through the vote kernels (coarse level + filter), on maps whose every pixel has its own label:
+    one wrong floor() anywhere changes a vote."""
+    W, H = 1920, 1080
+    rng = np.random.default_rng(5)
+    E = 4 * W * 2.0 ** -24
+    eps = [0.0, 1e-7, -1e-7, 0.9 * E, -0.9 * E, 1.1 * E, -1.1 * E, 3 * E, -3 * E, 0.3]
+    pos = _boundary_points(1728.0, 1728.0, W, H, (1.0, 2.9, 7.3), eps)
+    pos = np.concatenate([pos, scene.make_positions(200_000, 77)])
+    cams = [{"fx": 1728.0, "fy": 1728.0, "width": W, "height": H, "rotation": np.eye(3).tolist(), "position": [0, 0, 0]},
+            {"fx": 1728.0, "fy": 1728.0, "width": W, "height": H, "rotation": np.eye(3).tolist(), "position": [0.125, -0.25, 0]}]
+    cams += scene.make_cameras(6, W, H, convention="w2c")
+    segs = [rng.integers(-1, 150, size=(H, W), dtype=np.int32) for _ in cams]
+    for s in segs[:4]:
+        s[::2] = (s[::2] // 8) * 8            # some uniform 4x4 cells as well: both levels of the lookup are used
+    sizes = [(W, H)] * len(cams)
+    want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
+    for filt in (1, 0):
+        with gsx.Context(0) as c:
+            c.set_option("filter_project", filt)
+            got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()
+            assert np.array_equal(got, want), (filt, int((got != want).sum()))
+            c.vote_rewind()
+            c.vote_flush()
+            c.vote_tiebreak_keys()
+            assert np.array_equal(c.vote_labels_from_keys(), want), filt
 
 
 # ---- assign_labels ---------------------------------------------------------------------------------
@@ -927,28 +995,104 @@ def test_errors(ctx, gsx):
     assert (ctx.vote_finalize() == np.where(oracle.project_many(np.zeros((10, 3), np.float32), cam)[0] >= 0, 254, -1)).all()
 
 
-def test_full_size_properties(ctx):
-    """BASELINE config 3 size (3 M Gaussians, 200 views @1080p): size-independent properties —
-    the fused-labels kernel and the planes+keys path (two different kernels) agree on all 3 M
-    labels, and a 30k-Gaussian random sample equals the oracle."""
+from streaming_oracle import StreamingOracle as _StreamingOracle
+
+
+def test_full_size_properties(gsx):
+    """BASELINE configs[2] at its full size ON THE BENCHMARK'S OWN MAPS (3 M Gaussians, 200 views @1080p, Voronoi maps with
+    pixel-accurate boundaries: a fifth of the 4x4 cells are mixed, so the full-resolution lookup behind the coarse level, the
+    compact hand-over records and seg_expand all run), early vote on: all 3 M labels agree between the early vote's planes
+    form, its record-and-replay form, the one-piece kernel and the planes + keys path (four different kernel sets), and a
+    30 k-Gaussian random sample equals the oracle."""
+    import torch
     n, V, W, H = 3_000_000, 200, 1920, 1080
     pos = scene.make_positions(n, scene.BASE_SEED + 3)
     cams = scene.make_cameras(V, W, H, convention="w2c")
-    segs = [scene.make_segmap(H, W, 150, 3000 + v) for v in range(V)]
-    ctx.upload_positions(pos)
-    ctx.vote_begin(150, 0, V)
-    for v in range(V):
-        ctx.vote_view(cams[v], segs[v])
-    a = ctx.vote_finalize()
-    ctx.vote_rewind()
-    ctx.vote_flush()
-    ctx.vote_tiebreak_keys()
-    b = ctx.vote_labels_from_keys()
-    assert np.array_equal(a, b)
+    segs = [scene.make_segmap_gpu(torch, 0, H, W, 150, 3000 + v) for v in range(V)]
+    mixed = np.mean([(s[:H // 4 * 4:4, :W // 4 * 4:4] != s[3:H // 4 * 4:4, 3:W // 4 * 4:4]).mean() for s in segs[:5]])
+    assert mixed > 0.05                                    # (a lower bound on the mixed cells: corner pixels differ)
+    got = {}
+    for name, opts in (("planes", {}), ("replay", {"early_replay": 1}), ("one piece", {"early_vote": 0})):
+        with gsx.Context(0) as c:
+            for k, v in opts.items():
+                c.set_option(k, v)
+            c.profile(True)
+            c.upload_positions(pos)
+            c.vote_begin(150, 0, V)
+            for v in range(V):
+                c.vote_view(cams[v], segs[v])
+            got[name] = c.vote_finalize()
+            early = c.vote_early_views()
+            assert (early >= V // 2) == (name != "one piece"), (name, early)
+            assert _kernel_launches(c, "seg_expand") > 0 and c.vote_link_bytes() < 0.4 * V * W * H   # compact records crossed the link
+            if name == "planes":
+                assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_early_planes") == 1
+                c.vote_rewind()
+                c.vote_flush()
+                c.vote_tiebreak_keys()
+                got["keys"] = c.vote_labels_from_keys()
+    a = got["planes"]
+    for name in ("replay", "one piece", "keys"):
+        assert np.array_equal(a, got[name]), name
     sample = np.random.default_rng(1).choice(n, 30_000, replace=False)
     want = oracle.assign_labels(np.ascontiguousarray(pos[sample]), cams, segs, [(W, H)] * V, threads=0)
     assert np.array_equal(a[sample], want)
     assert (a != -1).mean() > 0.9 and len(np.unique(a)) == 151
+
+
+def test_config4_shape_batched_run(gsx):
+    """BASELINE configs[4]'s shape on one GPU, at a view count that needs the batched path: 10 M Gaussians x 520 views @4K
+    (three batches: two of 244 started early on the second stream while the later maps are handed over, a short last one),
+    pixel-accurate Voronoi maps made one at a time on the GPU and handed over as HOST int32 arrays (17 GB in all; only one
+    is alive at a time).  A 20 k-Gaussian sample equals the reference's vote, counted view by view by the oracle."""
+    import torch
+    n, V, W, H = 10_000_000, 520, 3840, 2160
+    pos = scene.make_positions(n, scene.BASE_SEED + 5)
+    cams = scene.make_cameras(V, W, H, convention="w2c")
+    sample = np.random.default_rng(4).choice(n, 20_000, replace=False)
+    so = _StreamingOracle(pos[sample], 150)
+    with gsx.Context(0) as c:
+        c.profile(True)
+        c.upload_positions(pos)
+        c.vote_begin(150, 0, V)
+        for v in range(V):
+            seg = scene.make_segmap_gpu(torch, 0, H, W, 150, 7000 + v, fast=True)
+            c.vote_view(cams[v], seg)
+            so.view(cams[v], seg, (W, H))
+        assert c.vote_early_views() == 488
+        got = c.vote_finalize()
+        assert _kernel_launches(c, "vote_early_counts") == 2 and _kernel_launches(c, "vote_fused_counts") == 1
+        want = so.labels()
+        assert np.array_equal(got[sample], want), int((got[sample] != want).sum())
+        assert (got != -1).mean() > 0.9
+        c.vote_rewind()                                    # the batches cut by the views that came (3 x 173/174), nothing early
+        assert np.array_equal(c.vote_finalize(), got)
+
+
+def test_early_batches_abandoned_at_a_batch_boundary(gsx):
+    """A run that announces 520 views and stops right where an early batch has just been started (or rewinds there): the
+    early count kernel may still be running on the second stream when vote_finalize cuts the views that came into other
+    batches and launches their count kernels into the same planes.  The main stream must be ordered behind the early
+    stage whenever its result is dropped; a large scene, so that the early kernel is still busy."""
+    n, V, W, H = 2_000_000, 520, 160, 96
+    pos = scene.make_positions(n, scene.BASE_SEED + 6)
+    cams = scene.make_cameras(V, W, H, convention="w2c")
+    segs = [scene.make_segmap(H, W, 6, 9700 + v, n_sites=12, cell=int(1 + v % 4)) for v in range(V)]
+    sample = np.random.default_rng(6).choice(n, 100_000, replace=False)
+    sub = np.ascontiguousarray(pos[sample])
+    for stop, rewind in ((244, False), (488, False), (488, True), (245, True)):
+        want = oracle.assign_labels(sub, cams[:stop], segs[:stop], [(W, H)] * stop, threads=0)
+        with gsx.Context(0) as c:
+            c.upload_positions(pos)
+            for rep in range(2):                           # the second run starts while the first one's stage may still be running
+                c.vote_begin(6, 0, V)
+                for v in range(stop):
+                    c.vote_view(cams[v], segs[v], (W, H))
+                assert c.vote_early_views() == (244 if stop < 488 else 488)
+                if rewind:
+                    c.vote_rewind()
+                got = c.vote_finalize()
+                assert np.array_equal(got[sample], want), (stop, rewind, rep, int((got[sample] != want).sum()))
 
 
 def test_config1_full_size_vote_and_raster(ctx):

@@ -14,7 +14,10 @@ pass() {
 pass stats --kernel-trace --stats || exit 1
 pass sq1 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS || exit 1
 pass sq2 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR || exit 1
-pass mem --kernel-trace --pmc FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE || exit 1
+# one TCC counter per pass: FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2 (MI355X_MICROARCH.md) - together they abort rocprofv3
+pass mem_fetch --kernel-trace --pmc FETCH_SIZE || exit 1
+pass mem_write --kernel-trace --pmc WRITE_SIZE || exit 1
+pass grbm --kernel-trace --pmc GRBM_GUI_ACTIVE || exit 1
 pass occ --kernel-trace --pmc SQ_LEVEL_WAVES SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU || echo "occ pass failed (counter names)" >&2
 python3 - <<PY > $OUT/summary.txt
 import csv, glob, collections, os

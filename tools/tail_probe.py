@@ -8,6 +8,12 @@ import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the timing-only option "ablate" exists in the experiments build only (`make -C 3d_gaussian_splatting_project_amd/csrc experiments`)
+_exp = os.path.join(ROOT, "3d_gaussian_splatting_project_amd", "libgsx_experiments.so")
+if os.path.exists(_exp):
+    os.environ.setdefault("GSX_LIBRARY", _exp)
+else:
+    raise SystemExit("build libgsx_experiments.so first: make -C 3d_gaussian_splatting_project_amd/csrc experiments")
 pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
 scene = pkg.scene
 import torch
