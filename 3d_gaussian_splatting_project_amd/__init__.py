@@ -6,7 +6,7 @@ The directory name starts with a digit, so import it with
 from . import _lib
 from ._lib import Camera, GsxError, build, lib
 from . import dist, scene
-from .labeler import Context, assign_labels_from_maps, bind_to_gpu_numa_node, load_cameras, project_gaussian
+from .labeler import Context, assign_labels_from_maps, bind_to_gpu_numa_node, camera_array, load_cameras, project_gaussian
 
-__all__ = ["Camera", "Context", "GsxError", "assign_labels_from_maps", "bind_to_gpu_numa_node", "build", "dist", "lib", "load_cameras",
+__all__ = ["Camera", "Context", "GsxError", "assign_labels_from_maps", "bind_to_gpu_numa_node", "build", "camera_array", "dist", "lib", "load_cameras",
            "project_gaussian", "scene"]

@@ -479,6 +479,11 @@ int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, co
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_import(c, n_parts, part_views, part_offsets, blobs, pool_all_dev, pool_all_bytes); });
 }
+int gsx_vote_import_uniform(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
+                            int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h, const void* pool_all_dev, int64_t pool_all_bytes) {
+    CTX_OR_FAIL(ctx);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_import_uniform(c, n_parts, part_views, part_offsets, cams, seg_w, seg_h, img_w, img_h, pool_all_dev, pool_all_bytes); });
+}
 int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size) {
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_slab_labels(c, slab, slabs, slab_size); });

@@ -97,6 +97,7 @@ struct alignas(64) ViewDesc {
     float hw32, hh32;       // half_w, half_h as floats (exact: the frame is <= 65535 pixels a side): the fp32 filter of the projection
     // ---- cold part: only read on the scale + clamp path (dls.py:270-286) ----
     double wscale, hscale;  // seg_w/img_w, seg_h/img_h                             (dls.py:270-271)
+    float xf[12];           // experiments (GSX_ABLATE & 64, timing only): fx R0, fy R1, R2 rows and fx t0, fy t1, t2 as floats
 };
 static_assert(sizeof(ViewDesc) == 256 && offsetof(ViewDesc, wscale) == 192, "ViewDesc layout");
 
@@ -293,6 +294,8 @@ int vote_views_device(Ctx* c, int n, const gsx_camera* cams, const void* const* 
 int vote_export(Ctx* c, int64_t reserve_bytes, void* blobs_out, void** pool_dev, int64_t* pool_bytes);
 int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                 const void* pool_all_dev, int64_t pool_all_bytes);
+int vote_import_uniform(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
+                        int seg_w, int seg_h, int img_w, int img_h, const void* pool_all_dev, int64_t pool_all_bytes);
 int vote_slab_labels(Ctx* c, int slab, int slabs, int64_t* slab_size);
 int host_threads(Ctx* c);
 int vote_flush_pending(Ctx* c);  // queue the DMA of packed host maps that are still waiting for their group to fill

@@ -642,6 +642,44 @@ __device__ __forceinline__ unsigned cull_bits(const CullMasks& k, int done) {
     return (unsigned)(word >> (done & 63)) & ((1u << U) - 1u);
 }
 
+#if GSX_ABLATE & 64
+// TIMING EXPERIMENT ONLY (results invalid): what an all-fp32 filter would cost - the camera-space point from twelve floats
+// (one s_load_dwordx16 instead of 176 bytes of fp64 descriptor), the exact path (full descriptor, fp64) only for the waves
+// with a lane near a pixel boundary.  Without the per-wave base point such a filter would need, its error bound is missing.
+struct ViewF32 {
+    float r0[3], r1[3], r2[3], t0, t1, t2, hw, hh;
+    int cam_w, cam_h, coarse_row_bytes;
+    unsigned coarse_delta;
+    long long seg_off;
+};
+__device__ __forceinline__ ViewF32 load_view_f32(const ViewDesc* __restrict__ vp) {
+    const char* q = reinterpret_cast<const char*>(vp);
+    v16i a = *reinterpret_cast<const v16i*>(q + 192);
+    v8i d = *reinterpret_cast<const v8i*>(q + 160);
+    v2i so = *reinterpret_cast<const v2i*>(q + 112);
+    asm volatile("" : "+s"(a), "+s"(d), "+s"(so));
+    ViewF32 r;
+    int w[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) w[k] = a[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r.r0[k] = __builtin_bit_cast(float, w[4 + k]);
+        r.r1[k] = __builtin_bit_cast(float, w[7 + k]);
+        r.r2[k] = __builtin_bit_cast(float, w[10 + k]);
+    }
+    r.t0 = __builtin_bit_cast(float, w[13]);
+    r.t1 = __builtin_bit_cast(float, w[14]);
+    r.t2 = __builtin_bit_cast(float, w[15]);
+    const int d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+    r.cam_w = d2, r.cam_h = d3, r.coarse_row_bytes = d4, r.coarse_delta = (unsigned)d5;
+    r.hw = __builtin_bit_cast(float, d6);
+    r.hh = __builtin_bit_cast(float, d7);
+    r.seg_off = __builtin_bit_cast(long long, so);
+    return r;
+}
+#endif
+
 // One chunk of U views (vb-1, vb-2, ..): bin[u] = the vote of this lane's Gaussian in view vb-1-u, or -1.
 // FULL: all U views exist (no index test).  culled: bit u set = the whole wave provably misses view vb-1-u.
 typedef const __attribute__((address_space(1))) uint8_t* global_u8_ptr;
@@ -662,6 +700,37 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
             const int v = vb - 1 - u;
             bin[u] = -1;  // (pixel[u] is only read where bin[u] == 255, i.e. where it was set below)
             if (((culled >> u) & 1u) || !(FULL || v >= 0)) continue;  // wave-uniform
+#if GSX_ABLATE & 64  // timing experiment only, see load_view_f32
+            if (DIV == kDivFiltCoarse) {
+                const ViewF32 f = load_view_f32(views + v);
+                const float Xf = (float)X, Yf = (float)Y, Zf = (float)Z;
+                const float zf = __builtin_fmaf(Xf, f.r2[0], __builtin_fmaf(Yf, f.r2[1], __builtin_fmaf(Zf, f.r2[2], f.t2)));
+                const bool pos = zf > 0.f;
+                if (__builtin_amdgcn_ballot_w64(pos) == 0) continue;
+                const float a0 = __builtin_fmaf(Xf, f.r0[0], __builtin_fmaf(Yf, f.r0[1], __builtin_fmaf(Zf, f.r0[2], f.t0)));
+                const float a1 = __builtin_fmaf(Xf, f.r1[0], __builtin_fmaf(Yf, f.r1[1], __builtin_fmaf(Zf, f.r1[2], f.t1)));
+                const float r = __builtin_amdgcn_rcpf(zf);
+                const float pxf = __builtin_fmaf(a0, r, f.hw), pyf = __builtin_fmaf(a1, r, f.hh);
+                const float dx = __builtin_amdgcn_fractf(pxf) - 0.5f, dy = __builtin_amdgcn_fractf(pyf) - 0.5f;
+                const bool cert = (zf >= 1e-12f) & (__builtin_fabsf(dx) <= filt_h) & (__builtin_fabsf(dy) <= filt_h);
+                int xi = cvt_floor_i32(pxf), yi = cvt_floor_i32(pyf);
+                bool vis = cert & ((unsigned)xi < (unsigned)f.cam_w) & ((unsigned)yi < (unsigned)f.cam_h);
+                long long seg_off = f.seg_off;
+                unsigned cdelta = f.coarse_delta;
+                int crb = f.coarse_row_bytes;
+                if (__builtin_amdgcn_ballot_w64(pos & !cert) != 0) {  // the exact path for the whole wave, full descriptor
+                    const ViewRegs vd = load_view(views + v);
+                    vis = project<kDivFlatSimple>(vd, X, Y, Z, xi, yi);
+                }
+                if (vis) {
+                    pixel[u] = (unsigned)xi | ((unsigned)yi << 16);
+                    const unsigned cx = (unsigned)xi >> 2, cy = (unsigned)yi >> 2;
+                    const unsigned coff = __umul24(cx >> 4, (unsigned)crb) + (cx & 15u) + (cy << 4);
+                    bin[u] = ((global_u8_ptr)((unsigned long long)seg_off + cdelta))[coff];
+                }
+                continue;
+            }
+#endif
             const ViewRegs vd = load_view(views + v);
             int xi, yi;
             if (DIV == kDivFiltCoarse ? project_filtered(vd, filt_h, X, Y, Z, xi, yi) : project<kDivFlatSimple>(vd, X, Y, Z, xi, yi)) {
@@ -1392,6 +1461,14 @@ void fill_view_desc(ViewDesc& vd, const gsx_camera* cam, int seg_w, int seg_h, i
     vd.cam_h = cam->height;
     vd.hw32 = (float)vd.half_w;  // exact for frames up to 2^24 pixels a side
     vd.hh32 = (float)vd.half_h;
+    for (int k = 0; k < 3; ++k) {
+        vd.xf[k] = (float)(vd.fx * vd.R[k]);
+        vd.xf[3 + k] = (float)(vd.fy * vd.R[3 + k]);
+        vd.xf[6 + k] = (float)vd.R[6 + k];
+    }
+    vd.xf[9] = (float)(vd.fx * vd.t[0]);
+    vd.xf[10] = (float)(vd.fy * vd.t[1]);
+    vd.xf[11] = (float)vd.t[2];
     vd.wscale = (double)seg_w / (double)img_w;
     vd.hscale = (double)seg_h / (double)img_h;
     vd.seg_w = seg_w;
@@ -2855,6 +2932,50 @@ int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* p
             d.seg_off += part_offsets[r];
             d.hw32 = (float)d.half_w;  // (never trusted from the blob: the filter's proof needs exactly these)
             d.hh32 = (float)d.half_h;
+        }
+    c->views.swap(all);
+    c->views_dirty = true;
+    c->pool_base = pool_all_dev;
+    c->first_view = 0;
+    c->n_flushed = 0;
+    c->labels_valid = false;
+    return GSX_OK;
+}
+
+// gsx_vote_import without the blobs: every rank of a run holds the whole camera list (cameras.json) and, when all maps of the
+// run share ONE geometry, knows where view k of part r lies in the gathered buffer - part_offsets[r] + k * stride, the stride
+// gsx_vote_view gives a map of that geometry under this context's options (all ranks run the same build with the same
+// options).  So the descriptors are derived here, the same way gsx_vote_view derives them (fill_view_desc + map_layout),
+// and the header exchange of the blobs and its host wait disappear from the protocol.
+int vote_import_uniform(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
+                        int seg_w, int seg_h, int img_w, int img_h, const void* pool_all_dev, int64_t pool_all_bytes) {
+    if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_import_uniform before vote_begin");
+    if (n_parts < 1 || !part_views || !part_offsets || !pool_all_dev || pool_all_bytes < 0)
+        return fail(c, GSX_E_INVALID, "vote_import_uniform: bad arguments");
+    if (seg_w < 1 || seg_h < 1 || img_w < 1 || img_h < 1 || seg_w > 65535 || seg_h > 65535)
+        return fail(c, GSX_E_INVALID, "vote_import_uniform: map %dx%d, image %dx%d", seg_w, seg_h, img_w, img_h);
+    long long total = 0;
+    for (int r = 0; r < n_parts; ++r) {
+        if (part_views[r] < 0 || part_offsets[r] < 0) return fail(c, GSX_E_INVALID, "vote_import_uniform: negative count or offset");
+        total += part_views[r];
+    }
+    if (total > 65535) return fail(c, GSX_E_RANGE, "vote_import_uniform: %lld views exceed 65535", total);
+    if (total > 0 && !cams) return fail(c, GSX_E_INVALID, "vote_import_uniform: cams is NULL");
+    const MapLayout L = map_layout(seg_w, seg_h, c->opt_seg_tiled != 0, c->opt_seg_coarse && c->bins <= 255);  // as view_prologue
+    const size_t stride = (L.map_bytes + 255) / 256 * 256;
+    std::vector<ViewDesc> all((size_t)total);
+    size_t k = 0;
+    for (int r = 0; r < n_parts; ++r)
+        for (int v = 0; v < part_views[r]; ++v, ++k) {
+            const unsigned long long off = (unsigned long long)part_offsets[r] + (unsigned long long)v * stride;
+            if (off + L.map_bytes > (unsigned long long)pool_all_bytes)
+                return fail(c, GSX_E_INVALID, "vote_import_uniform: view %zu (part %d) lies outside the gathered pool", k, r);
+            ViewDesc& d = all[k];
+            fill_view_desc(d, &cams[k], L.w, L.h, img_w, img_h);
+            d.seg_off = (long long)off;
+            d.seg_row_bytes = L.strip_bytes;
+            d.coarse_row_bytes = L.cstrip_bytes;
+            d.coarse_delta = (unsigned)L.coarse_off;
         }
     c->views.swap(all);
     c->views_dirty = true;

@@ -357,6 +357,15 @@ class GpuGatherShard(_GpuShard):
     def import_all(self, part_views, part_offsets, blobs, pool_all):
         self.ctx.vote_import(part_views, part_offsets, blobs, pool_all.data_ptr(), pool_all.numel())
 
+    def import_uniform(self, part_views, part_offsets, cameras, map_size, image_size, pool_all):
+        self.ctx.vote_import_uniform(part_views, part_offsets, cameras, map_size, image_size, pool_all.data_ptr(), pool_all.numel())
+
+    def event(self):
+        """a timing event recorded on the ctx stream (torch's current stream must be the ctx stream: `with shard.stream()`)"""
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
     def slab_labels(self, rank, world):
         sn = self.ctx.vote_slab_labels(rank, world)
         kp, _ = self.ctx.keys_device()
@@ -401,6 +410,9 @@ class HostGatherShard:
 
     def import_all(self, part_views, part_offsets, blobs, pool_all):
         self.shard.import_all(part_views, part_offsets, blobs, pool_all.numpy())
+
+    def import_uniform(self, part_views, part_offsets, cameras, map_size, image_size, pool_all):
+        self.shard.import_uniform(part_views, part_offsets, cameras, map_size, image_size, pool_all.numpy())
 
     def slab_labels(self, rank, world):
         return torch.from_numpy(self.shard.slab_labels(rank, world))
@@ -453,42 +465,71 @@ def exchange_labels_gather(shard, group=None, to_host=True, out=None, cap_views=
         return shard.finish(full, to_host, out=out)
 
 
+def chunk_bounds(n_max, chunks):
+    """Cut points 0 = b_0 < b_1 < .. < b_C = n_max of the ranks' view blocks (a function of (n_max, chunks) alone: every rank
+    derives the same).  Balanced chunks and a SHORT last one (an eighth of the block, at least one view): the last chunk's
+    all-gather is the one no hand-over hides, so it should carry little."""
+    n_max, chunks = int(n_max), max(1, int(chunks))
+    if n_max <= 0:
+        return [0]
+    if chunks == 1 or n_max < 2 * chunks:
+        m = -(-n_max // chunks)
+        return list(range(0, n_max, m)) + [n_max]
+    tail = max(1, n_max // 8)
+    body = n_max - tail
+    return [body * k // (chunks - 1) for k in range(chunks - 1)] + [body, n_max]
+
+
 class GatherPipeline:
     """Protocol v4 with the all-gather of the packed maps OVERLAPPED with the hand-over of the later views.
 
-        pipe = GatherPipeline(shard, total_views)          # after gsx_vote_begin
+        pipe = GatherPipeline(shard, total_views, cameras=all_cameras, map_size=(w, h))     # after gsx_vote_begin
         for view in my block:  ctx.vote_view(...);  pipe.after_view()
         labels = pipe.finish(out=...)
 
     Every rank must own the block view_range(total_views, rank, world) of views.  The ranks' blocks are cut into C chunks
-    of m views; as soon as a rank has staged the views of chunk j it joins all_gather number j (async, on the ctx stream:
-    the DMAs of the later views keep flowing, RCCL's stream picks the chunk up behind the copies that fill it).  The
-    sequence of collectives is a function of (total_views, world) alone: one agreement all_gather (the ranks' map strides),
-    C chunk all_gathers, the header all_gather, the labels all_gather - identical on every rank whatever happens locally.
-    If the maps are not of ONE geometry (strides differ between ranks, or a rank finds its own pool irregular at the end),
-    every rank learns it from gathered data and all fall back to the plain gather of exchange_labels_gather."""
+    (chunk_bounds: balanced, the last one short); as soon as a rank has staged the views of chunk j it joins all_gather
+    number j (async, on the ctx stream: the DMAs of the later views keep flowing, RCCL's stream picks the chunk up behind
+    the copies that fill it).  The sequence of collectives is a function of (total_views, world) alone, identical on every
+    rank whatever happens locally.
 
-    def __init__(self, shard, total_views, group=None, chunks=4, assume_uniform=False):
-        """assume_uniform: the caller guarantees that EVERY view of EVERY rank has the same map geometry (a capture from one
-        camera model).  The agreement collective and its host wait are then skipped - provided every rank owns at least
-        one view, which all ranks can tell from (total_views, world).  A rank that finds its own pool irregular still
-        reports it in the header and all ranks fall back together; a geometry that differs BETWEEN ranks would however make
-        the chunk collectives disagree in size, which is why this is a promise and not the default."""
+    Two ways to learn the other ranks' views:
+      * cameras + map_size given (round 3; a capture from ONE camera model, which is what a cameras.json describes): every rank
+        derives every view's descriptor itself (gsx_vote_import_uniform) - no header exchange, no host wait anywhere between the
+        first vote_view and the labels.  Collectives: C chunk all_gathers, one 4-byte flag all_gather nobody waits for until
+        the labels are there, the labels all_gather.  A rank whose own pool is not what the schedule assumes (fewer views than
+        its share, a map of another geometry) raises its flag; every rank sees the flags next to the labels and all fall back
+        to the plain gather together.
+      * otherwise (round 2): one agreement all_gather of the ranks' map strides (skipped with assume_uniform), the chunk
+        all_gathers, a header all_gather carrying the view blobs (the host waits for it), the labels all_gather; mixed
+        geometries fall back to the plain gather of exchange_labels_gather.
+    timing=True: finish() leaves self.phases_ms (host stamps + events on the ctx stream)."""
+
+    def __init__(self, shard, total_views, group=None, chunks=4, assume_uniform=False, cameras=None, map_size=None, image_size=None,
+                 timing=False):
         self.shard, self.group, self.total = shard, group, int(total_views)
-        self.assume_uniform = bool(assume_uniform)
+        self.local_views = cameras is not None and map_size is not None
+        self.assume_uniform = bool(assume_uniform) or self.local_views
+        self.cameras, self.map_size = cameras, map_size
+        self.image_size = image_size if image_size is not None else map_size
+        if self.local_views and len(cameras) != self.total:
+            raise ValueError(f"GatherPipeline: {len(cameras)} cameras for {self.total} views")
         on = dist.is_initialized()
         self.world = dist.get_world_size(group) if on else 1
         self.rank = dist.get_rank(group) if on else 0
         self.active = _collectives_needed(self.world)
         self.n = [hi - lo for lo, hi in (view_range(self.total, r, self.world) for r in range(self.world))]
         n_max = max(self.n) if self.n else 0
-        self.m = max(1, -(-n_max // max(1, int(chunks))))       # views per chunk
-        self.C = -(-n_max // self.m) if n_max else 0            # chunk all_gathers every rank will issue
+        self.bounds = chunk_bounds(n_max, chunks)               # views [b_j, b_j+1) of every rank's block form chunk j
+        self.C = len(self.bounds) - 1                           # chunk all_gathers every rank will issue
         self.stride = None       # bytes per staged map, agreed by all ranks; 0: no pipelining (fallback)
         self.next_chunk = 0
         self.works = []
         self.pool_all = None
         self.pool_src = None
+        self.timing = bool(timing)
+        self.phases_ms = None
+        self._t_first = self._t_last = None
 
     # -- agreement on the map stride: the first collective of every rank -------------------------------------------------
     def _agree(self):
@@ -508,42 +549,74 @@ class GatherPipeline:
             self.stride = have[0] if have and all(v == have[0] and v > 0 and v % 256 == 0 for v in have) else 0
         if self.stride:
             with _stream_of(self.shard):
-                need = self.C * self.m * self.stride
-                self.pool_src = self.shard.pool(need)                     # reserves: every chunk reads m * stride bytes
+                need = self.bounds[-1] * self.stride
+                self.pool_src = self.shard.pool(need)                     # reserves: chunk j reads (b_j+1 - b_j) * stride bytes
                 self.pool_all = self.shard.pool_all(self.world * need)
+
+    def _chunk_at(self, j):
+        """byte offset of chunk j's region in the gathered buffer, bytes per rank in it"""
+        return self.world * self.bounds[j] * self.stride, (self.bounds[j + 1] - self.bounds[j]) * self.stride
 
     def _issue(self, j):
         if self.stride:
-            cb = self.m * self.stride
+            at, cb = self._chunk_at(j)
             self.shard.flush()
             with _stream_of(self.shard):
-                w = _all_gather_into(self.pool_all[j * self.world * cb:(j + 1) * self.world * cb], self.pool_src[j * cb:(j + 1) * cb],
+                w = _all_gather_into(self.pool_all[at:at + self.world * cb], self.pool_src[self.bounds[j] * self.stride:self.bounds[j] * self.stride + cb],
                                      self.group, async_op=True)
             if w is not None:
                 self.works.append(w)
         self.next_chunk = j + 1
 
     def after_view(self):
+        if self.timing:
+            import time
+            self._t_last = time.perf_counter()
+            if self._t_first is None:
+                self._t_first = self._t_last
         if not self.active:
             return
         nv, _ = self.shard.staged()
         if self.stride is None:
             self._agree()
         me = self.n[self.rank]
-        while self.next_chunk < self.C and nv >= min((self.next_chunk + 1) * self.m, me):
+        while self.next_chunk < self.C and nv >= min(self.bounds[self.next_chunk + 1], me):
             self._issue(self.next_chunk)
 
+    def _parts(self, relative):
+        """(views, byte offset) of every (rank, chunk) part in global view order = rank-major, chunk-minor.  relative: the offset
+        the round-2 blobs are rebased by (they hold offsets inside the exporting rank's own pool, b_j * stride + ..)."""
+        pv, po = [], []
+        for r in range(self.world):
+            for j in range(self.C):
+                k = min(max(self.n[r] - self.bounds[j], 0), self.bounds[j + 1] - self.bounds[j])
+                if k:
+                    at, cb = self._chunk_at(j)
+                    pv.append(k)
+                    po.append(at + r * cb - (self.bounds[j] * self.stride if relative else 0))
+        return np.asarray(pv, np.int32), np.asarray(po, np.int64)
+
+    def _mark(self, events, name):
+        if self.timing and hasattr(self.shard, "event"):
+            events.append((name, self.shard.event()))
+
     def finish(self, to_host=True, out=None):
+        import time
         shard, world, rank = self.shard, self.world, self.rank
         if not self.active:
             return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
+        t_fin = time.perf_counter()
         if self.stride is None:
             self._agree()                                   # a rank without views gets here first
         while self.next_chunk < self.C:
             self._issue(self.next_chunk)
-        # header: counts, bytes, blobs - and whether my pool is what the chunk schedule assumed
         nv, used = shard.staged()
         regular = bool(self.stride) and nv == self.n[rank] and used == nv * self.stride
+        events = []
+        self._mark(events, "start")
+        if self.local_views:
+            return self._finish_local(regular, events, t_fin, to_host, out)
+        # header: counts, bytes, blobs - and whether my pool is what the chunk schedule assumed
         cap = max(1, max(self.n))
         mine = shard.header(cap)
         flag = torch.tensor([1 if regular else 0], dtype=torch.uint8, device=mine.device)
@@ -561,20 +634,68 @@ class GatherPipeline:
         if not ok:                                          # every rank sees the same flags: all take the plain path together
             return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
         blobs = np.concatenate([heads[r, _HDR:_HDR + 256 * int(part_views[r])] for r in range(world)])
-        cb = self.m * self.stride
-        pv, po = [], []
-        for r in range(world):                              # global view order = rank-major, chunk-minor
-            for j in range(self.C):
-                k = min(max(self.n[r] - j * self.m, 0), self.m)
-                if k:
-                    pv.append(k)
-                    po.append((j * (world - 1) + r) * cb)   # chunk j of rank r sits at (j*world + r)*cb; its blobs say j*cb + ..
+        pv, po = self._parts(relative=True)
         with _stream_of(shard):
-            shard.import_all(np.asarray(pv, np.int32), np.asarray(po, np.int64), blobs, self.pool_all[:self.C * world * cb])
+            self._mark(events, "gathers")
+            shard.import_all(pv, po, blobs, self.pool_all[:world * self.bounds[-1] * self.stride])
             slab = shard.slab_labels(rank, world)
+            self._mark(events, "vote")
             full = shard.labels_all(slab.numel() * world)
             _all_gather_into(full, slab, self.group)
-            return shard.finish(full, to_host, out=out)
+            self._mark(events, "labels")
+            res = shard.finish(full, to_host, out=out)
+        self._phases(events, t_fin)
+        return res
+
+    def _finish_local(self, regular, events, t_fin, to_host, out):
+        shard, world, rank = self.shard, self.world, self.rank
+        dev = shard.device()
+        # the flags: on torch's own stream, nobody waits for them before the labels are on the host
+        flag = torch.tensor([1 if regular else 0], dtype=torch.int32, device=dev)
+        flags = torch.empty(world, dtype=torch.int32, device=dev)
+        fw = _all_gather_into(flags, flag, self.group, async_op=True)
+        with _stream_of(shard):                             # Work.wait() makes the CURRENT stream wait: the ctx stream
+            for w in self.works:
+                w.wait()
+            self.works = []
+            self._mark(events, "gathers")
+            res = None
+            if self.stride:
+                pv, po = self._parts(relative=False)
+                shard.import_uniform(pv, po, self.cameras, self.map_size, self.image_size,
+                                     self.pool_all[:world * self.bounds[-1] * self.stride])
+                slab = shard.slab_labels(rank, world)
+                self._mark(events, "vote")
+                full = shard.labels_all(slab.numel() * world)
+                _all_gather_into(full, slab, self.group)
+                self._mark(events, "labels")
+                res = shard.finish(full, to_host, out=out)   # the host waits here (labels D2H), for the first time in the run
+        if fw is not None:
+            fw.wait()
+        ok = bool(self.stride) and bool(flags.cpu().numpy().all())
+        if not ok:                                          # every rank sees the same flags: all take the plain path together
+            return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
+        self._phases(events, t_fin)
+        return res
+
+    def _phases(self, events, t_fin):
+        """ms: hand_over = first vote_view -> last one returned (host); then, on the ctx stream: chunk all_gathers still
+        running when finish() was called; import + slab vote; labels all_gather; labels to the host (D2H + widening)."""
+        if not self.timing:
+            return
+        import time
+        t_end = time.perf_counter()
+        ph = {"hand_over": None if self._t_first is None else (t_fin - self._t_first) * 1e3,
+              "finish_host_total": (t_end - t_fin) * 1e3}
+        ev = dict(events)
+        if all(k in ev for k in ("start", "gathers", "vote", "labels")):
+            for e in ev.values():
+                e.synchronize()
+            ph["gathers_exposed"] = ev["start"].elapsed_time(ev["gathers"])
+            ph["import_and_slab_vote"] = ev["gathers"].elapsed_time(ev["vote"])
+            ph["labels_all_gather"] = ev["vote"].elapsed_time(ev["labels"])
+            ph["labels_to_host"] = max(0.0, ph["finish_host_total"] - ev["start"].elapsed_time(ev["labels"]))
+        self.phases_ms = {k: (None if v is None else round(float(v), 4)) for k, v in ph.items()}
 
 
 def view_range(n_views_total, rank, world):

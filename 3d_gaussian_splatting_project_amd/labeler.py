@@ -22,6 +22,11 @@ if os.environ.get("GSX_NO_FAST_BINDING"):
     _fast = None
 
 
+def camera_array(cameras):
+    """ctypes array of gsx_camera from Camera structs and/or cameras.json dicts"""
+    return (Camera * len(cameras))(*[c if isinstance(c, Camera) else Camera.from_dict(c) for c in cameras])
+
+
 def load_cameras(camera_file):
     """cameras.json -> list of dicts (reference: deep_learning_segmentation.py:17-22)."""
     with open(camera_file, "r") as f:
@@ -305,6 +310,16 @@ class Context:
         bl = np.ascontiguousarray(blobs, np.uint8)
         check(self._lib.gsx_vote_import(self.h, len(pv), pv.ctypes.data, po.ctypes.data, bl.ctypes.data if bl.size else None,
                                         C.c_void_p(pool_all_ptr), int(pool_all_bytes)), self.h)
+
+    def vote_import_uniform(self, part_views, part_offsets, cams, map_size, image_size, pool_all_ptr, pool_all_bytes):
+        """gsx_vote_import_uniform: cams = the cameras of ALL views in global order (Camera structs, a ctypes array of them, or
+        dicts); map_size / image_size = (width, height) shared by every view of the run."""
+        pv = np.ascontiguousarray(part_views, np.int32)
+        po = np.ascontiguousarray(part_offsets, np.int64)
+        arr = cams if isinstance(cams, C.Array) else camera_array(cams)
+        check(self._lib.gsx_vote_import_uniform(self.h, len(pv), pv.ctypes.data, po.ctypes.data, C.addressof(arr) if len(arr) else None,
+                                                int(map_size[0]), int(map_size[1]), int(image_size[0]), int(image_size[1]),
+                                                C.c_void_p(pool_all_ptr), int(pool_all_bytes)), self.h)
 
     def vote_slab_labels(self, slab, slabs):
         """-> slab size S; the slab's labels (Morton order) are the first S words at keys_device()."""

@@ -202,6 +202,7 @@ def main():
     pos = scene.make_positions(n, scene.BASE_SEED + 3)
     cams_all = scene.make_cameras(total_views, W, H, convention="w2c")
     cam_structs = [Camera.from_dict(c) for c in cams_all[first:last]]
+    cams_all_arr = pkg.camera_array(cams_all)      # every rank holds the whole camera list (cameras.json)
     host_segs = make_segmaps(scene, torch, device, H, W, args.classes, [3000 + first + v for v in range(V)], args.seg_cell)
     ctx = pkg.Context(device)
     for kv in args.opt:
@@ -224,16 +225,17 @@ def main():
     exchange = {"gather": pkg.dist.exchange_labels_gather, "sparse": pkg.dist.exchange_labels_sparse,
                 "a2a": pkg.dist.exchange_labels_a2a, "allreduce": pkg.dist.exchange_labels}.get(mode)
 
-    def step():
+    def step(timing=False):
         """The metric's span: first vote_view submit -> labels on the host."""
         ctx.vote_begin(args.classes, first, total_views)
         if mode == "pipelined":
-            pipe = pkg.dist.GatherPipeline(shard, total_views, assume_uniform=True)   # one synthetic camera model
+            # one camera model: every rank derives all view descriptors from the shared camera list (no header exchange)
+            pipe = pkg.dist.GatherPipeline(shard, total_views, cameras=cams_all_arr, map_size=(W, H), timing=timing)
             for v in range(V):
                 ctx.vote_view(cam_structs[v], host_segs[v])
                 pipe.after_view()
             pipe.finish(out=labels_buf)
-            return
+            return pipe.phases_ms
         for v in range(V):
             ctx.vote_view(cam_structs[v], host_segs[v])
         if not multi:
@@ -271,6 +273,37 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n * total_views / (elapsed / args.steps)
     labels_main = labels_buf.copy()
+    # ---- N > 1: where a step's time goes.  Extra steps OUTSIDE the timed region (the events' host waits would perturb it):
+    # per phase the median over the steps, then the MAX over the ranks; per-rank hand-over rate of the int32 maps. ------------
+    phases = None
+    if mode == "pipelined":
+        rows, walls = [], []
+        for _ in range(max(3, min(args.steps, 7))):
+            fence()
+            ts = time.perf_counter()
+            ph = step(timing=True)
+            walls.append((time.perf_counter() - ts) * 1e3)
+            if ph:
+                rows.append(ph)
+        keys = ["hand_over", "gathers_exposed", "import_and_slab_vote", "labels_all_gather", "labels_to_host"]
+        if rows and all(all(r.get(k) is not None for k in keys) for r in rows):
+            med = [float(np.median([r[k] for r in rows])) for k in keys] + [float(np.median(walls))]
+            t = torch.tensor(med, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            mx = [float(x) for x in t.tolist()]
+            raw_bytes = float(sum(s_.nbytes for s_ in host_segs))
+            mine = torch.tensor([raw_bytes / (med[0] * 1e-3) / 1e9 if med[0] > 0 else 0.0], dtype=torch.float64, device=t.device)
+            alls = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(alls, mine)
+            phases = {k: round(v, 4) for k, v in zip(keys, mx[:-1])}
+            phases["sum"] = round(sum(mx[:-1]), 4)
+            phases["step_ms_of_these_steps"] = round(mx[-1], 4)
+            phases["note"] = ("max over ranks of each rank's median over extra steps run after the timed region: hand_over = first "
+                              "vote_view -> last one returned (host; the chunk all_gathers of the earlier views run underneath); then on "
+                              "the ctx stream: chunk all_gathers still running at that point, import + vote of this rank's slab, "
+                              "all_gather of the slab labels; labels_to_host = D2H (one byte per label) + widening + Python")
+            phases["host_ingest_GBps_of_int32_maps_per_rank"] = [round(float(a.item()), 2) for a in alls]
+
     labels_check = None
     if mode in ("gather", "pipelined"):
         # after the import every rank holds every view: a plain single-GPU vote of ALL Gaussians on this rank must give
@@ -320,17 +353,29 @@ def main():
             k_ms = total_ms / launches
             alg = alg_bytes(name)
             achieved = alg / (k_ms * 1e-3) / 1e9
-            cached = {}
+            cached, stale = {}, None
             tpath = os.path.join(ROOT, "profiles", "counters.json")   # PMC figures of the committed rocprofv3 runs
             if os.path.exists(tpath):
                 try:
-                    cached = json.load(open(tpath)).get(name, {})
+                    allc = json.load(open(tpath))
+                    cached = allc.get(name, {})
+                    # the figures belong to ONE build of the kernels and ONE early-vote split: quote them only for those
+                    import hashlib
+                    src = os.path.join(ROOT, "3d_gaussian_splatting_project_amd", "csrc", "vote.hip")
+                    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+                    st = allc.get("_stamp", {})
+                    if st.get("vote_hip_sha16") != sha:
+                        stale = f"profiles/counters.json was taken on another build of csrc/vote.hip ({st.get('vote_hip_sha16')} != {sha})"
+                    elif name != "vote_fused_labels" and st.get("early_views") != int(early_views):
+                        stale = f"profiles/counters.json was taken with {st.get('early_views')} early views, this run chose {int(early_views)}"
                 except Exception:
                     cached = {}
+            if stale:
+                cached = {"stale": stale}
             return {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": cached.get("hbm_bytes_per_launch"),
-                    "traffic_source": cached.get("source", None) and f"cached profile figure, not measured in this run: {cached.get('source')}",
+                    "traffic_source": cached.get("stale") or (cached.get("source", None) and f"cached profile figure, not measured in this run: {cached.get('source')}"),
                     "kernel_ms": round(k_ms, 4), "launches": launches, "algorithmic_bytes": int(alg),
                     "second_bound": cached.get("valu_f64")}
 
@@ -417,7 +462,7 @@ def main():
         sizes = [(W, H)] * V
         cams_cpu = cams_all[:V]
         threads = min(oracle.max_threads(), len(os.sched_getaffinity(0)), args.cpu_threads)
-        m = min(n, args.cpu_sample)
+        m = min(n, args.cpu_sample, max(20_000, int(4e9 // max(1, V))))   # bounded: <= ~30 s of CPU work whatever the shape
         sub = np.ascontiguousarray(pos[:m])
         t1 = time.perf_counter()
         want = oracle.assign_labels(sub, cams_cpu, host_segs, sizes, threads=threads)
@@ -492,7 +537,11 @@ def main():
                        "cpu_quota_throttling_in_timed_region": None if thr0 is None or thr1 is None else
                        {"scheduler_periods": thr1[0] - thr0[0], "throttled_periods": thr1[1] - thr0[1],
                         "throttled_ms": round((thr1[2] - thr0[2]) / 1e3, 1)},
-                       "exchanged_labels_equal_single_gpu_vote": labels_check},
+                       "exchanged_labels_equal_single_gpu_vote": labels_check,
+                       "rccl_world": (world if args.backend == "nccl" else None) if multi else None,
+                       "collective_backend": args.backend if multi else None,
+                       "phases_ms": phases,
+                       "library_options": dict(kv.split("=") for kv in args.opt) or None},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "vs_cpu_baseline": None if cpu is None else cpu["gpu_speedup_all_cores"],

@@ -294,6 +294,13 @@ int64_t gsx_vote_early_views(const gsx_ctx* ctx);
  * Replaces the views staged so far; global view order = part order.  Blobs are validated against the pool size. */
 int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                     const void* pool_all_dev, int64_t pool_all_bytes);
+/* gsx_vote_import for a run whose maps all share ONE geometry (seg_w x seg_h, images img_w x img_h: a capture from one
+ * camera model), without the blobs: every rank holds the whole camera list (load_cameras, dls.py:17-22) and derives the
+ * descriptors itself, exactly as gsx_vote_view does - cams[k] is the camera of global view k (part order), view v of part r
+ * lies at part_offsets[r] + v * (the pool stride gsx_vote_view gives a map of this geometry under this context's options:
+ * all ranks must run the same build with the same options).  No exchange of view blobs is needed then. */
+int gsx_vote_import_uniform(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
+                            int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h, const void* pool_all_dev, int64_t pool_all_bytes);
 /* votes the Gaussians [slab * S, min(n, (slab+1) * S)) of the Morton order over all staged views, S = *slab_size =
  * ceil(n / slabs) rounded up to 256; labels (int32, Morton order) at gsx_vote_keys_device()[0 .. S). */
 int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size);

@@ -534,6 +534,18 @@ class NumpyGatherShard:
                 seg = unpack_map_numpy(pool_all[int(part_offsets[r]) + off:], w, h)
                 self.views.append((cam, seg, (iw, ih)))
 
+    def import_uniform(self, part_views, part_offsets, cameras, map_size, image_size, pool_all):
+        """the views from the shared camera list and ONE map geometry (dist.GatherPipeline with cameras=...): view v of part r
+        lies at part_offsets[r] + v * stride of the gathered pool"""
+        w, h = int(map_size[0]), int(map_size[1])
+        stride = (pack_map_numpy(np.zeros((h, w), np.int32), self.n_classes)[0].size + 255) // 256 * 256
+        self.views, k = [], 0
+        for r, nv in enumerate(part_views):
+            for v in range(int(nv)):
+                seg = unpack_map_numpy(pool_all[int(part_offsets[r]) + v * stride:], w, h)
+                self.views.append((cameras[k], seg, (int(image_size[0]), int(image_size[1]))))
+                k += 1
+
     def slab_labels(self, rank, world):
         sn = ((self.n + world - 1) // world + 255) // 256 * 256 or 256
         lo, hi = min(self.n, rank * sn), min(self.n, (rank + 1) * sn)

@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/../3d_gaussian_splatting_project_amd/csrc"
 make experiments >/dev/null
 mkdir -p ../../tools/ablate
-for m in 2 32; do
+for m in ${ABLATE_MASKS:-2 32}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -Wno-unused-result --offload-arch=gfx950 -ffp-contract=off -DGSX_EXPERIMENTS -DGSX_ABLATE=$m -c vote.hip -o /tmp/vote_ablate_$m.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../tools/ablate/libgsx_$m.so exp/gsx_api.o /tmp/vote_ablate_$m.o exp/sort.o exp/render.o exp/blend.o exp/kmeans.o exp/ply_io.o exp/host_pack.o -lpthread
 done

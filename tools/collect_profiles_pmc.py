@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Runs ON THE GPU BOX right after tools/gpu_profile_r02.sh: reduces the raw rocprofv3 CSVs (too large to travel) of
+"""Runs ON THE GPU BOX right after tools/gpu_profile_pmc.sh: reduces the raw rocprofv3 CSVs (too large to travel) of
 gpurun_out/prof_<tag>/ to gpurun_out/prof_<tag>/summary/: the kernel stats table, and per kernel of interest the
 per-launch means of every collected counter (summed over the XCD / SE / instance rows rocprofv3 emits per dispatch).
-Usage: tools/collect_profiles_r02.py gpurun_out/prof_r02a"""
+Usage: tools/collect_profiles_pmc.py gpurun_out/prof_r03a"""
 import collections
 import csv
 import glob
@@ -30,6 +30,9 @@ f = one("stats/*/*kernel_stats.csv")
 if f:
     shutil.copy(f, os.path.join(dst, "kernel_stats.csv"))
 shutil.copy(os.path.join(src, "command.txt"), os.path.join(dst, "command.txt"))
+for extra in ("bench_line.json", "vote_hip_sha16.txt"):   # the profiled run's own JSON line and the stamp of the kernels' source
+    if os.path.exists(os.path.join(src, extra)):
+        shutil.copy(os.path.join(src, extra), os.path.join(dst, extra))
 
 out = {k: {"kernel": None, "counters": {}} for k in KERNELS}
 for sub in sorted(glob.glob(os.path.join(src, "pmc_*"))):
