@@ -374,6 +374,7 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
         rec1[i] = r1;
         rec2[i] = r2;
         tile_rect[i] = rect;
+        if (i == 0) minmax[3] = (int)rect;  // splat 0's rectangle, kept apart: the blend's epilogue draws splat 0 again even if bucket_kernel drops it
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -775,7 +776,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, c->r_sat.ensure((size_t)ntiles));
     constexpr size_t kSmallBytes = 256 + (size_t)kConsumedSlots * 128;
     GSX_HIP(c, c->r_small.ensure(kSmallBytes));
-    // [0]=min [1]=max [2]=dropped [3]=pad, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
+    // [0]=min [1]=max [2]=dropped [3]=splat 0's tile rectangle, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
     // counters 128 B apart (summed below)
     int* small = c->r_small.as<int>();
     unsigned long long* small64 = reinterpret_cast<unsigned long long*>(small);

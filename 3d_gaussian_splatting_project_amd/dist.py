@@ -48,6 +48,11 @@ class _GpuShard:
     def __init__(self, ctx):
         self.ctx = ctx
         self._ext = None
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if _collectives_needed(world) and hasattr(ctx, "set_option"):
+            # a rank of a multi-rank run never holds ALL views when it votes its own block: the early vote's result would always be
+            # discarded (1.2 GB of planes and 1.6 ms of GPU work competing with the all-gather on rank 0, whose block starts at view 0)
+            ctx.set_option("early_vote", 0)
 
     def stream(self):
         if self._ext is None:

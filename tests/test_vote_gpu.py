@@ -1228,6 +1228,26 @@ for rep, chunks in enumerate((4, 1, 9, 3)):
     out = np.empty(n, np.int32)
     got = pipe.finish(out=out)
     ok[f"pipeline{chunks}"] = bool(got is out and np.array_equal(out, want) and pipe.stride > 0 and pipe.next_chunk == pipe.C)
+# round 3: every rank derives the descriptors of all views from the shared camera list (gsx_vote_import_uniform): no header
+# exchange; with the phase timing on; and a rank whose pool is not what the schedule assumes makes all ranks fall back
+for rep, chunks in enumerate((4, 1, 6)):
+    ctx.vote_begin(12, 0, V)
+    pipe = pkg.dist.GatherPipeline(pkg.dist.GpuGatherShard(ctx), V, chunks=chunks, cameras=cams, map_size=(W, H), timing=rep == 0)
+    for k, (cam, seg) in enumerate(zip(cams, segs)):
+        ctx.vote_view(cam, torch.from_numpy(seg).cuda() if (k + rep) % 2 else seg)
+        pipe.after_view()
+    out = np.empty(n, np.int32)
+    got = pipe.finish(out=out)
+    ok[f"local{chunks}"] = bool(got is out and np.array_equal(out, want) and pipe.stride > 0 and pipe.next_chunk == pipe.C)
+    if rep == 0:
+        ph = pipe.phases_ms
+        ok["phases"] = bool(ph and all(ph.get(k) is not None and ph[k] >= 0 for k in ("hand_over", "gathers_exposed", "import_and_slab_vote", "labels_all_gather", "labels_to_host")))
+ctx.vote_begin(12, 0, V)
+pipe = pkg.dist.GatherPipeline(pkg.dist.GpuGatherShard(ctx), V, cameras=cams, map_size=(W, H))
+for cam, seg in zip(cams[:-1], segs[:-1]):                      # one view short of its share: the flag gather says so
+    ctx.vote_view(cam, seg)
+    pipe.after_view()
+ok["local_short_rank_falls_back"] = bool(np.array_equal(pipe.finish(), oracle.assign_labels(pos, cams[:-1], segs[:-1], [(W, H)] * (V - 1), threads=0)))
 # ... and its fallback when the maps are not of one geometry
 ctx.vote_begin(12, 0, V)
 pipe = pkg.dist.GatherPipeline(pkg.dist.GpuGatherShard(ctx), V)
