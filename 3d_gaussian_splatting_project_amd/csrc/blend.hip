@@ -49,13 +49,14 @@ __device__ __forceinline__ void blend_one(Accum& acc, float fxp, float fyp, cons
 // returns without reading or writing the canvas: the previous phase's pixels are final.  (Round 2 re-read and re-wrote the
 // whole canvas in the last phase: 66 MB of the 184 MB a 1080p frame moved.)
 __device__ __forceinline__ bool tile_has_nothing_to_do(int2 range, const uint8_t* __restrict__ sat, int tile, int tx, int ty, int first,
-                                                       int last, const int* __restrict__ dropped, long long n) {
+                                                       int last, const int* __restrict__ dropped, const int* __restrict__ pre,
+                                                       long long n) {
     if (first) return false;
     const bool opaque = sat[tile] != 0;
     if (range.y > range.x && !opaque) return false;
     if (!last) return true;
     if (opaque || n <= 0 || dropped[0] <= 0) return true;
-    const uint32_t r = (uint32_t)dropped[1];  // splat 0's tile rectangle (pre_kernel; dropped = &small[2], small[3] = the rectangle)
+    const uint32_t r = (uint32_t)pre[2];  // splat 0's tile rectangle (pre_kernel)
     const int tx0 = r & 255u, tx1 = (r >> 8) & 255u, ty0 = (r >> 16) & 255u, ty1 = r >> 24;
     return tx < tx0 || tx > tx1 || ty < ty0 || ty > ty1;
 }
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
                                                               const float4* __restrict__ rec0,
                                                               const float4* __restrict__ rec1,
                                                               const float2* __restrict__ rec2, int W, int H, int tiles_x,
-                                                              const int* __restrict__ dropped, long long n,
+                                                              const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                               unsigned long long* __restrict__ consumed,
                                                               float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
                                                               int last) {
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     const float fxp = (float)px + 0.5f;               // pixel centre, GL window coordinates
     const float fyp = (float)H - ((float)py + 0.5f);  // window y is up; image row py counts from the top
     const int2 range = ranges[tile];
-    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, n)) return;
+    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum acc{0.f, 0.f, 0.f, 0.f};                    // gl.clear to (0,0,0,0), gs.js:1608
     if (!first && inside) {
         const float4 prev = image[(size_t)py * W + px];
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
                                                                 const float4* __restrict__ rec0,
                                                                 const float4* __restrict__ rec1,
                                                                 const float2* __restrict__ rec2, int W, int H, int tiles_x,
-                                                                const int* __restrict__ dropped, long long n,
+                                                                const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                                 unsigned long long* __restrict__ consumed,
                                                                 float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
                                                                 int last) {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     fyp.x = (float)H - ((float)py0 + 0.5f);
     fyp.y = (float)H - ((float)py1 + 0.5f);
     const int2 range = ranges[tile];
-    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, n)) return;
+    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 acc{};
     if (!first) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
                                                                 const float4* __restrict__ rec0,
                                                                 const float4* __restrict__ rec1,
                                                                 const float2* __restrict__ rec2, int W, int H, int tiles_x,
-                                                                const int* __restrict__ dropped, long long n,
+                                                                const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                                 unsigned long long* __restrict__ consumed,
                                                                 float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
                                                                 int last) {
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     fyB.y = (float)H - ((float)(row + 12) + 0.5f);
     const bool in[4] = {px < W && row < H, px < W && row + 8 < H, px < W && row + 4 < H, px < W && row + 12 < H};
     const int2 range = ranges[tile];
-    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, n)) return;
+    if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 accA{}, accB{};
     if (!first) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -371,15 +372,15 @@ int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int ti
     if (c->opt_blend_pk2 == 2) {
         hipLaunchKernelGGL(blend4_kernel, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+                           c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     } else if (c->opt_blend_pk2) {
         hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+                           c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     } else {
         hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
-                           (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+                           c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     }
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;

@@ -180,6 +180,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         if (value < 2 || value > 64) return gsx::fail(c, GSX_E_INVALID, "set_option: render_phase_ratio must be in [2,64]");
         c->opt_render_phase_ratio = (int)value;
     }
+    else if (k == "render_multi_pre") c->opt_render_multi_pre = value != 0;
     else if (k == "render_frames") {
         if (value < 1 || value > Ctx::kMaxFrames) return gsx::fail(c, GSX_E_INVALID, "set_option: render_frames must be in [1,%d]", (int)Ctx::kMaxFrames);
         c->opt_render_frames = (int)value;

@@ -254,6 +254,18 @@ struct Ctx {
     int r_W = 0, r_H = 0;
     DevBuf r_ranges, r_small, r_scan;
     DevBuf r_depth, r_bucket, r_rect, r_count, r_offset, r_rec0, r_rec1, r_rec2;
+    DevBuf r_pre;                        // int[4]: min depth, max depth, splat 0's tile rectangle (written by the pre pass)
+    // gsx_render_views with several frames in flight: ONE pre pass per group of frames (pre_multi_kernel) writes the per-view
+    // records of all of them; a frame's records live in one of three rotating sets so that the pass for group g + 1 can run
+    // while the frames of group g (and stragglers of g - 1) still read theirs
+    struct PreSet {
+        DevBuf depth, rect, rec0, rec1, rec2, pre;
+    };
+    static constexpr int kPreSets = 3;
+    PreSet r_sets[kPreSets];
+    hipEvent_t r_pre_ev[kPreSets] = {nullptr, nullptr, nullptr};  // recorded behind the pre pass that filled set s
+    int r_pre_ext = -1;                  // >= 0: this frame's pre pass has been run for it into r_sets[r_pre_ext] (render_view skips its own)
+    int opt_render_multi_pre = 1;        // gsx_render_views: one pre pass per group of frames in flight (0: every frame its own)
     DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
     DevBuf r_tile_order;                 // blend launch order (longest list first)
     int r_sorted_in = 0;

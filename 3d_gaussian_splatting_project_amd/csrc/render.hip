@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -181,9 +182,23 @@ __global__ __launch_bounds__(kRB) void sh_pack_kernel(const uint32_t* __restrict
     }
 }
 
-// colour of one splat seen from the camera position: clamp(0.5 + SH(dir), 0, 1) per channel
-__device__ __forceinline__ void sh_color(const float* __restrict__ coef, long long n, long long i, int deg, float px, float py,
-                                         float pz, float cpx, float cpy, float cpz, float rgb[3]) {
+// colour of one splat seen from the camera position: clamp(0.5 + SH(dir), 0, 1) per channel.
+// Coef: where coefficient (k, c) of the splat comes from - CoefMem reads the planes (one view at a time), CoefRegs holds the
+// splat's coefficients in registers (pre_multi_kernel: read once, used by every view of the group).  Same operations in the
+// same order either way.
+struct CoefMem {
+    const float* __restrict__ coef;
+    long long n, i;
+    __device__ __forceinline__ float get(int k, int c) const { return coef[((size_t)k * 3 + c) * (size_t)n + (size_t)i]; }
+};
+struct CoefRegs {
+    float v[48];
+    __device__ __forceinline__ float get(int k, int c) const { return v[3 * k + c]; }
+};
+
+template <class Coef>
+__device__ __forceinline__ void sh_color(const Coef& cf, int deg, float px, float py, float pz, float cpx, float cpy, float cpz,
+                                         float rgb[3]) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
     const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
@@ -214,9 +229,8 @@ __device__ __forceinline__ void sh_color(const float* __restrict__ coef, long lo
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (k < K) {
-            const float* p = coef + (size_t)k * 3 * n + i;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * p[(size_t)c * n] : acc[c] + b[k] * p[(size_t)c * n];
+            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * cf.get(0, c) : acc[c] + b[k] * cf.get(k, c);
         }
     }
 #pragma unroll
@@ -267,13 +281,136 @@ __device__ __forceinline__ bool tile_touches(float cx, float cy, float g0x, floa
 
 static constexpr uint32_t kEmptyRect = 1u;  // tx0 = 1 > tx1 = 0: covers no tile
 
-// One pass over the texel pairs per view: depth key (gs.js:436-441: ((vp2 x + vp6 y + vp10 z) * 4096) | 0, fp64, and
-// its min / max over ALL splats), vertex shader (gs.js:696-750, fp32 in the oracle's operation order), colour (the
-// reference's rgba8, or the float SH colour for the splats that are actually drawn) and the tile rectangle of the
-// ellipse's bounding box.  One atomic pair per workgroup for the depth range (same-address atomics serialise in L2).
+// One splat in one view: depth key (gs.js:436-441: ((vp2 x + vp6 y + vp10 z) * 4096) | 0, fp64), vertex shader (gs.js:696-750,
+// fp32 in the oracle's operation order), colour (the reference's rgba8, or the float SH colour for the splats that are
+// actually drawn) and the tile rectangle of the ellipse's bounding box.  need_color(): called before the SH colour is
+// evaluated (pre_multi_kernel fetches the splat's coefficients there, once for all views).
+struct PreOut {
+    int depth;
+    uint32_t rect;
+    float4 r0, r1;
+    float2 r2;
+};
+
+template <class Coef, class Need>
+__device__ __forceinline__ PreOut pre_one(const uint4 t0, const uint4 t1, const ViewUniforms& u, bool sh_on, int sh_deg, float cpx,
+                                          float cpy, float cpz, const Coef& cf, Need need_color) {
+    PreOut o;
+    const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
+    o.depth = js_toint32((u.vp2 * (double)cx_ + u.vp6 * (double)cy_ + u.vp10 * (double)cz_) * 4096.0);
+    o.rect = kEmptyRect;
+    o.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    o.r1 = o.r0;
+    o.r2 = make_float2(0.f, 0.f);
+    // ---- vertex shader, fp32 ----
+    float cam[4], p2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cam[k] = u.view[k] * cx_ + u.view[4 + k] * cy_ + u.view[8 + k] * cz_ + u.view[12 + k] * 1.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p2[k] = u.proj[k] * cam[0] + u.proj[4 + k] * cam[1] + u.proj[8 + k] * cam[2] + u.proj[12 + k] * cam[3];
+    const float clip = 1.2f * p2[3];
+    bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
+    if (drawn) {
+        const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
+        const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
+        const float u3x = half_to_float(t1.z & 0xffffu), u3y = half_to_float(t1.z >> 16);
+        const float V[3][3] = {{u1x, u1y, u2x}, {u1y, u2y, u3x}, {u2x, u3x, u3y}};
+        const float ja = u.fx / cam[2], jb = -(u.fx * cam[0]) / (cam[2] * cam[2]);
+        const float jc = -u.fy / cam[2], jd = (u.fy * cam[1]) / (cam[2] * cam[2]);
+        float ta[3], tb[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ta[k] = u.view[4 * k + 0] * ja + u.view[4 * k + 1] * 0.0f + u.view[4 * k + 2] * jb;
+            tb[k] = u.view[4 * k + 0] * 0.0f + u.view[4 * k + 1] * jc + u.view[4 * k + 2] * jd;
+        }
+        float a0[3], a1[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a0[k] = ta[0] * V[k][0] + ta[1] * V[k][1] + ta[2] * V[k][2];
+            a1[k] = tb[0] * V[k][0] + tb[1] * V[k][1] + tb[2] * V[k][2];
+        }
+        const float c00 = a0[0] * ta[0] + a0[1] * ta[1] + a0[2] * ta[2];
+        const float c01 = a1[0] * ta[0] + a1[1] * ta[1] + a1[2] * ta[2];
+        const float c11 = a1[0] * tb[0] + a1[1] * tb[1] + a1[2] * tb[2];
+        const float mid = (c00 + c11) / 2.0f;
+        const float hx = (c00 - c11) / 2.0f;
+        const float radius = sqrtf(hx * hx + c01 * c01);
+        const float l1 = mid + radius, l2 = mid - radius;
+        if (l2 < 0.0f) drawn = false;  // gs.js:736
+        const float dx = c01, dy = l1 - c00;
+        const float dl = sqrtf(dx * dx + dy * dy);
+        const float ux = dx / dl, uy = dy / dl;
+        const float s1 = fminf(sqrtf(2.0f * l1), 1024.0f), s2 = fminf(sqrtf(2.0f * l2), 1024.0f);
+        const float mx = s1 * ux, my = s1 * uy;    // majorAxis
+        const float nx = s2 * uy, ny = s2 * -ux;   // minorAxis
+        float fade = p2[2] / p2[3] + 1.0f;
+        fade = fade < 0.0f ? 0.0f : (fade > 1.0f ? 1.0f : fade);
+        const float ndcx = p2[0] / p2[3], ndcy = p2[1] / p2[3];
+        const float wcx = (ndcx + 1.0f) * 0.5f * u.W;  // GL window coordinates, y up
+        const float wcy = (ndcy + 1.0f) * 0.5f * u.H;
+        const float m2 = mx * mx + my * my, n2 = nx * nx + ny * ny;
+        const float big = 3.0e38f;
+        if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
+        if (drawn) {
+            // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
+            const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
+            const float top = u.H - wcy;  // image row coordinate of the centre
+            int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
+            int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
+            x0 = max(x0, 0);
+            y0 = max(y0, 0);
+            x1 = min(x1, (int)u.W - 1);
+            y1 = min(y1, (int)u.H - 1);
+            if (x1 >= x0 && y1 >= y0) {
+                const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
+                o.rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
+                // the colour is only needed for splats that reach a pixel: 192 B of SH coefficients per splat.
+                // (Deferring it further, to the splats a depth phase really bins, was measured: those are visited in
+                // DEPTH order, the coefficient reads become gathers and cost 9x what the skipped splats save.)
+                float col[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
+                if (sh_on) {
+                    need_color();
+                    float rgb[3];
+                    sh_color(cf, sh_deg, cx_, cy_, cz_, cpx, cpy, cpz, rgb);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) col[k] = fade * rgb[k];
+                }
+                o.r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
+                o.r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
+                o.r2 = make_float2(col[2], col[3]);
+            }
+        }
+    }
+    return o;
+}
+
+// workgroup-wide min / max of the depth keys -> one atomic pair per workgroup (same-address atomics serialise in L2)
+__device__ __forceinline__ void depth_range_to(int lo, int hi, int* __restrict__ pre, int* slo /*[4]*/, int* shi /*[4]*/) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, __shfl_xor(lo, o));
+        hi = max(hi, __shfl_xor(hi, o));
+    }
+    __syncthreads();  // (the previous view's values have been read)
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&pre[0], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
+        atomicMax(&pre[1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
+    }
+}
+
+// One pass over the texel pairs per view.  pre[4] = {min depth, max depth, splat 0's tile rectangle, -}: min / max over ALL
+// splats (gs.js:436-441); the rectangle of splat 0 is kept apart because the blend's epilogue draws splat 0 again even when
+// bucket_kernel drops it (and clears its entry of tile_rect).
 __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
                                                    const float* __restrict__ sh_coef, int sh_deg, float cpx, float cpy, float cpz,
-                                                   int* __restrict__ depth, int* __restrict__ minmax,
+                                                   int* __restrict__ depth, int* __restrict__ pre,
                                                    float4* __restrict__ rec0, float4* __restrict__ rec1,
                                                    float2* __restrict__ rec2, uint32_t* __restrict__ tile_rect) {
     __shared__ int slo[4], shi[4];
@@ -282,114 +419,77 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
     // workgroup of a 12 k-workgroup launch kept the L2 busy for 0.2 ms after the last wave had finished)
     for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
         const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
-        const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
-        const int d = js_toint32((u.vp2 * (double)cx_ + u.vp6 * (double)cy_ + u.vp10 * (double)cz_) * 4096.0);
-        depth[i] = d;
-        lo = min(lo, d);
-        hi = max(hi, d);
-        uint32_t rect = kEmptyRect;
-        // ---- vertex shader, fp32 ----
-        float cam[4], p2[4];
+        const CoefMem cf{sh_coef, n, i};
+        const PreOut o = pre_one(t0, t1, u, sh_coef != nullptr, sh_deg, cpx, cpy, cpz, cf, [] {});
+        depth[i] = o.depth;
+        lo = min(lo, o.depth);
+        hi = max(hi, o.depth);
+        rec0[i] = o.r0;
+        rec1[i] = o.r1;
+        rec2[i] = o.r2;
+        tile_rect[i] = o.rect;
+        if (i == 0) pre[2] = (int)o.rect;
+    }
+    depth_range_to(lo, hi, pre, slo, shi);
+}
+
+// The same for up to kPreViews views in ONE pass over the scene: a splat's texel pair and its SH coefficients (224 B at
+// degree 3) are read once and every view of the group gets its records from them - gsx_render_views keeps several frames in
+// flight, and each of them used to stream the whole scene again (4 x 816 MB at 3 M splats).  The coefficients are fetched
+// when the first view that draws the splat asks for a colour.  Per view the operations are pre_kernel's, on the same
+// operands: the frames are bit-identical.
+static constexpr int kPreViews = Ctx::kMaxFrames;
+struct PreMultiArgs {
+    ViewUniforms u[kPreViews];
+    float cam[kPreViews][3];
+    int* depth[kPreViews];
+    int* pre[kPreViews];
+    float4* rec0[kPreViews];
+    float4* rec1[kPreViews];
+    float2* rec2[kPreViews];
+    uint32_t* rect[kPreViews];
+    int nv;
+};
+
+__global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict__ tex, long long n, const float* __restrict__ sh_coef,
+                                                         int sh_deg, PreMultiArgs a) {
+    __shared__ int slo[4], shi[4];
+    int lo[kPreViews], hi[kPreViews];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) cam[k] = u.view[k] * cx_ + u.view[4 + k] * cy_ + u.view[8 + k] * cz_ + u.view[12 + k] * 1.0f;
+    for (int v = 0; v < kPreViews; ++v) lo[v] = 2147483647, hi[v] = -2147483647 - 1;
+    const int K = (sh_deg + 1) * (sh_deg + 1);
+    for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
+        const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
+        CoefRegs cf;
+        bool have = false;
+        auto fetch = [&] {
+            if (have) return;
+            have = true;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) p2[k] = u.proj[k] * cam[0] + u.proj[4 + k] * cam[1] + u.proj[8 + k] * cam[2] + u.proj[12 + k] * cam[3];
-        const float clip = 1.2f * p2[3];
-        bool drawn = !(p2[2] < -clip || p2[0] < -clip || p2[0] > clip || p2[1] < -clip || p2[1] > clip);
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-        float2 r2 = make_float2(0.f, 0.f);
-        if (drawn) {
-            const float u1x = half_to_float(t1.x & 0xffffu), u1y = half_to_float(t1.x >> 16);
-            const float u2x = half_to_float(t1.y & 0xffffu), u2y = half_to_float(t1.y >> 16);
-            const float u3x = half_to_float(t1.z & 0xffffu), u3y = half_to_float(t1.z >> 16);
-            const float V[3][3] = {{u1x, u1y, u2x}, {u1y, u2y, u3x}, {u2x, u3x, u3y}};
-            const float ja = u.fx / cam[2], jb = -(u.fx * cam[0]) / (cam[2] * cam[2]);
-            const float jc = -u.fy / cam[2], jd = (u.fy * cam[1]) / (cam[2] * cam[2]);
-            float ta[3], tb[3];
+            for (int k = 0; k < 16; ++k)
+                if (k < K) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ta[k] = u.view[4 * k + 0] * ja + u.view[4 * k + 1] * 0.0f + u.view[4 * k + 2] * jb;
-                tb[k] = u.view[4 * k + 0] * 0.0f + u.view[4 * k + 1] * jc + u.view[4 * k + 2] * jd;
-            }
-            float a0[3], a1[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                a0[k] = ta[0] * V[k][0] + ta[1] * V[k][1] + ta[2] * V[k][2];
-                a1[k] = tb[0] * V[k][0] + tb[1] * V[k][1] + tb[2] * V[k][2];
-            }
-            const float c00 = a0[0] * ta[0] + a0[1] * ta[1] + a0[2] * ta[2];
-            const float c01 = a1[0] * ta[0] + a1[1] * ta[1] + a1[2] * ta[2];
-            const float c11 = a1[0] * tb[0] + a1[1] * tb[1] + a1[2] * tb[2];
-            const float mid = (c00 + c11) / 2.0f;
-            const float hx = (c00 - c11) / 2.0f;
-            const float radius = sqrtf(hx * hx + c01 * c01);
-            const float l1 = mid + radius, l2 = mid - radius;
-            if (l2 < 0.0f) drawn = false;  // gs.js:736
-            const float dx = c01, dy = l1 - c00;
-            const float dl = sqrtf(dx * dx + dy * dy);
-            const float ux = dx / dl, uy = dy / dl;
-            const float s1 = fminf(sqrtf(2.0f * l1), 1024.0f), s2 = fminf(sqrtf(2.0f * l2), 1024.0f);
-            const float mx = s1 * ux, my = s1 * uy;    // majorAxis
-            const float nx = s2 * uy, ny = s2 * -ux;   // minorAxis
-            float fade = p2[2] / p2[3] + 1.0f;
-            fade = fade < 0.0f ? 0.0f : (fade > 1.0f ? 1.0f : fade);
-            const float ndcx = p2[0] / p2[3], ndcy = p2[1] / p2[3];
-            const float wcx = (ndcx + 1.0f) * 0.5f * u.W;  // GL window coordinates, y up
-            const float wcy = (ndcy + 1.0f) * 0.5f * u.H;
-            const float m2 = mx * mx + my * my, n2 = nx * nx + ny * ny;
-            const float big = 3.0e38f;
-            if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
-            if (drawn) {
-                // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
-                const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
-                const float top = u.H - wcy;  // image row coordinate of the centre
-                int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
-                int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
-                x0 = max(x0, 0);
-                y0 = max(y0, 0);
-                x1 = min(x1, (int)u.W - 1);
-                y1 = min(y1, (int)u.H - 1);
-                if (x1 >= x0 && y1 >= y0) {
-                    const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
-                    rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
-                    // the colour is only needed for splats that reach a pixel: 192 B of SH coefficients per splat.
-                    // (Deferring it further, to the splats a depth phase really bins, was measured: those are visited in
-                    // DEPTH order, the coefficient reads become gathers and cost 9x what the skipped splats save.)
-                    float col[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
-                    if (sh_coef) {
-                        float rgb[3];
-                        sh_color(sh_coef, n, i, sh_deg, cx_, cy_, cz_, cpx, cpy, cpz, rgb);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) col[k] = fade * rgb[k];
-                    }
-                    r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
-                    r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
-                    r2 = make_float2(col[2], col[3]);
+                    for (int c = 0; c < 3; ++c) cf.v[3 * k + c] = sh_coef[((size_t)k * 3 + c) * (size_t)n + (size_t)i];
                 }
+        };
+#pragma unroll
+        for (int v = 0; v < kPreViews; ++v) {
+            if (v < a.nv) {  // wave-uniform
+                const PreOut o = pre_one(t0, t1, a.u[v], sh_coef != nullptr, sh_deg, a.cam[v][0], a.cam[v][1], a.cam[v][2], cf, fetch);
+                a.depth[v][i] = o.depth;
+                lo[v] = min(lo[v], o.depth);
+                hi[v] = max(hi[v], o.depth);
+                a.rec0[v][i] = o.r0;
+                a.rec1[v][i] = o.r1;
+                a.rec2[v][i] = o.r2;
+                a.rect[v][i] = o.rect;
+                if (i == 0) a.pre[v][2] = (int)o.rect;
             }
         }
-        rec0[i] = r0;
-        rec1[i] = r1;
-        rec2[i] = r2;
-        tile_rect[i] = rect;
-        if (i == 0) minmax[3] = (int)rect;  // splat 0's rectangle, kept apart: the blend's epilogue draws splat 0 again even if bucket_kernel drops it
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, __shfl_xor(lo, o));
-        hi = max(hi, __shfl_xor(hi, o));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        slo[threadIdx.x >> 6] = lo;
-        shi[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicMin(&minmax[0], min(min(slo[0], slo[1]), min(slo[2], slo[3])));
-        atomicMax(&minmax[1], max(max(shi[0], shi[1]), max(shi[2], shi[3])));
-    }
+    for (int v = 0; v < kPreViews; ++v)
+        if (v < a.nv) depth_range_to(lo[v], hi[v], a.pre[v], slo, shi);
 }
 
 // 16-bit depth bucket (gs.js:443-447) once the depth range is known; doubles as the (key, value) initialisation of the
@@ -747,6 +847,41 @@ int upload_sh(Ctx* c, const float* f_rest, int deg) {
 int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int tiles_y, const int* dropped_dev,
                  unsigned long long* consumed_dev, uint8_t* sat, int first_phase, int last_phase);  // blend.hip
 
+static const int kPreInit[4] = {2147483647, -2147483647 - 1, (int)kEmptyRect, 0};  // depth min / max, splat 0's rectangle (static: outlives the copy)
+
+static int ensure_pre_set(Ctx* c, Ctx::PreSet& ps, long long n) {
+    const size_t n4 = 4 * (size_t)n;
+    GSX_HIP(c, ps.depth.ensure(n4));
+    GSX_HIP(c, ps.rect.ensure(n4));
+    GSX_HIP(c, ps.rec0.ensure(16 * (size_t)n));
+    GSX_HIP(c, ps.rec1.ensure(16 * (size_t)n));
+    GSX_HIP(c, ps.rec2.ensure(8 * (size_t)n));
+    GSX_HIP(c, ps.pre.ensure(16));
+    return GSX_OK;
+}
+
+static ViewUniforms view_uniforms(const gsx_camera* cam, int W, int H) {
+    ViewUniforms u{};
+    double view[16], proj[16], vp[16];
+    js_view_matrix(cam, view);
+    js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
+    js_multiply4(proj, view, vp);
+    u.vp2 = vp[2];
+    u.vp6 = vp[6];
+    u.vp10 = vp[10];
+    for (int k = 0; k < 16; ++k) {  // gl.uniformMatrix4fv: JS numbers -> f32
+        u.view[k] = (float)view[k];
+        u.proj[k] = (float)proj[k];
+    }
+    u.fx = (float)cam->fx;
+    u.fy = (float)cam->fy;
+    u.W = (float)W;
+    u.H = (float)H;
+    u.tiles_x = (W + 15) / 16;
+    u.tiles_y = (H + 15) / 16;
+    return u;
+}
+
 // One frame.  Per view: pre_kernel (depth keys, vertex shader, colours, tile rectangles), bucket_kernel, the level-1
 // sort of the splats by depth bucket; then the splats are rasterized FRONT TO BACK IN DEPTH PHASES (the nearest
 // n/r^(K-1) splats, the next ones up to n/r^(K-2), .., the rest): each phase bins its splats into the tiles that are not
@@ -776,7 +911,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, c->r_sat.ensure((size_t)ntiles));
     constexpr size_t kSmallBytes = 256 + (size_t)kConsumedSlots * 128;
     GSX_HIP(c, c->r_small.ensure(kSmallBytes));
-    // [0]=min [1]=max [2]=dropped [3]=splat 0's tile rectangle, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
+    // [2]=dropped, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
     // counters 128 B apart (summed below)
     int* small = c->r_small.as<int>();
     unsigned long long* small64 = reinterpret_cast<unsigned long long*>(small);
@@ -790,33 +925,23 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, hipStreamSynchronize(c->stream));
         return GSX_OK;
     }
-    ViewUniforms u{};
-    double view[16], proj[16], vp[16];
-    js_view_matrix(cam, view);
-    js_proj_matrix(cam->fx, cam->fy, (double)W, (double)H, proj);
-    js_multiply4(proj, view, vp);
-    u.vp2 = vp[2];
-    u.vp6 = vp[6];
-    u.vp10 = vp[10];
-    for (int k = 0; k < 16; ++k) {  // gl.uniformMatrix4fv: JS numbers -> f32
-        u.view[k] = (float)view[k];
-        u.proj[k] = (float)proj[k];
-    }
-    u.fx = (float)cam->fx;
-    u.fy = (float)cam->fy;
-    u.W = (float)W;
-    u.H = (float)H;
-    u.tiles_x = tiles_x;
-    u.tiles_y = tiles_y;
+    const ViewUniforms u = view_uniforms(cam, W, H);
     const size_t n4 = 4 * (size_t)n;
-    GSX_HIP(c, c->r_depth.ensure(n4));
+    const bool ext_pre = c->r_pre_ext >= 0;  // gsx_render_views ran this frame's pre pass (pre_multi_kernel) into one of the rotating sets
+    {
+        Ctx::PreSet& ps = c->r_sets[ext_pre ? c->r_pre_ext : 0];  // a frame on its own uses set 0
+        int rcs = ensure_pre_set(c, ps, n);
+        if (rcs) return rcs;
+        c->r_depth.alias(ps.depth);
+        c->r_rect.alias(ps.rect);
+        c->r_rec0.alias(ps.rec0);
+        c->r_rec1.alias(ps.rec1);
+        c->r_rec2.alias(ps.rec2);
+        c->r_pre.alias(ps.pre);
+    }
     GSX_HIP(c, c->r_bucket.ensure(n4));
-    GSX_HIP(c, c->r_rect.ensure(n4));
     GSX_HIP(c, c->r_count.ensure(n4));
     GSX_HIP(c, c->r_offset.ensure(n4));
-    GSX_HIP(c, c->r_rec0.ensure(16 * (size_t)n));
-    GSX_HIP(c, c->r_rec1.ensure(16 * (size_t)n));
-    GSX_HIP(c, c->r_rec2.ensure(8 * (size_t)n));
     GSX_HIP(c, c->r_d0.ensure(n4));
     GSX_HIP(c, c->r_d1.ensure(n4));
     GSX_HIP(c, c->r_d2.ensure(n4));
@@ -843,18 +968,18 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_vals0.ensure(4 * cap));
         GSX_HIP(c, c->r_vals1.ensure(4 * cap));
         GSX_HIP(c, hipMemsetAsync(c->r_sat.p, 0, (size_t)ntiles, c->stream));
-        static const int kInit[kSmallBytes / 4] = {2147483647, -2147483647 - 1};  // depth min / max; counters 0 (static: outlives the copy)
-        GSX_HIP(c, hipMemcpyAsync(small, kInit, sizeof kInit, hipMemcpyHostToDevice, c->stream));
-        {
+        GSX_HIP(c, hipMemsetAsync(small, 0, kSmallBytes, c->stream));  // counters
+        if (!ext_pre) {  // (a frame that is redone because a phase overflowed the pair buffers keeps the pre pass's records)
+            GSX_HIP(c, hipMemcpyAsync(c->r_pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
             ProfScope ps(c, "render_pre");
             hipLaunchKernelGGL(pre_kernel, dim3(std::min<unsigned>(grid_for(n), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, (float)cam->p[0], (float)cam->p[1],
-                               (float)cam->p[2], c->r_depth.as<int>(), small, c->r_rec0.as<float4>(), c->r_rec1.as<float4>(),
+                               (float)cam->p[2], c->r_depth.as<int>(), c->r_pre.as<int>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(),
                                c->r_rec2.as<float2>(), c->r_rect.as<uint32_t>());
         }
         {
             ProfScope ps(c, "render_bucket");
-            hipLaunchKernelGGL(bucket_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_depth.as<int>(), n, small,
+            hipLaunchKernelGGL(bucket_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_depth.as<int>(), n, c->r_pre.as<int>(),
                                c->r_bucket.as<uint32_t>(), c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_rect.as<uint32_t>(),
                                small + 2);
         }
@@ -972,13 +1097,20 @@ static int twin_sync_scene(Ctx* c, int k) {
 }
 
 void render_release_twin(Ctx* c) {
+    for (hipEvent_t& e : c->r_pre_ev)
+        if (e) {
+            (void)hipEventDestroy(e);
+            e = nullptr;
+        }
     for (Ctx*& t : c->twins) {
         if (!t) continue;
         (void)hipStreamSynchronize(t->stream);
         for (DevBuf* b : {&t->r_tex, &t->r_shc, &t->r_image, &t->r_ranges, &t->r_small, &t->r_scan, &t->r_depth, &t->r_bucket, &t->r_rect,
                           &t->r_count, &t->r_offset, &t->r_rec0, &t->r_rec1, &t->r_rec2, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
-                          &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist})
+                          &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist, &t->r_pre})
             b->release();
+        for (Ctx::PreSet& ps : t->r_sets)
+            for (DevBuf* b : {&ps.depth, &ps.rect, &ps.rec0, &ps.rec1, &ps.rec2, &ps.pre}) b->release();
         (void)hipStreamDestroy(t->stream);
         delete t;
         t = nullptr;
@@ -1005,16 +1137,84 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
     int rc = GSX_OK;
     for (int f = 1; f < F; ++f)
         if ((rc = twin_sync_scene(c, f - 1))) return rc;
-    // frame k is rendered by stream k % F: stream 0 is the context's own (this thread), the others have a host thread each
+    // frame k is rendered by stream k % F: stream 0 is the context's own (this thread), the others have a host thread each.
+    // Group g = the frames g * F .. g * F + F - 1.  With the option render_multi_pre the pre pass of a whole group is ONE launch
+    // (pre_multi_kernel) on stream 0, issued by this thread ahead of its own frame of the previous group, into record set
+    // g % 3 of every frame's context; the other frames wait for it through an event.  Host-side ordering (an event must have
+    // been recorded before another thread may wait for it, a set must not be rewritten while a frame still reads it) goes
+    // through two counters: pre_issued (groups whose pass has been launched) and done[f] (frames context f has completed -
+    // render_view returns only after its end-of-frame synchronisation).
     int rcs[Ctx::kMaxFrames] = {};  // GSX_OK == 0
     unsigned long long P[Ctx::kMaxFrames] = {}, used[Ctx::kMaxFrames] = {};
+    const bool multi = c->opt_render_multi_pre != 0 && c->rn > 0;
+    const int groups = (n + F - 1) / F;
+    std::atomic<int> pre_issued{0}, done[Ctx::kMaxFrames];
+    std::atomic<bool> failed{false};
+    for (auto& d : done) d.store(0);
+    Ctx* ctxs[Ctx::kMaxFrames] = {c};
+    for (int f = 1; f < F; ++f) ctxs[f] = c->twins[f - 1];
+    if (multi) {
+        for (int f = 0; f < F; ++f)
+            for (Ctx::PreSet& ps : ctxs[f]->r_sets)
+                if ((rc = ensure_pre_set(c, ps, c->rn))) return rc;
+        for (int s = 0; s < Ctx::kPreSets; ++s)
+            if (!c->r_pre_ev[s]) GSX_HIP(c, hipEventCreateWithFlags(&c->r_pre_ev[s], hipEventDisableTiming));
+    }
+    auto issue_pre = [&](int g) -> int {  // this thread only; stream 0
+        // set g % 3 was last read by the frames of group g - 3: every context must have completed them
+        for (int f = 0; f < F; ++f)
+            while (done[f].load(std::memory_order_acquire) < std::min(g - 2, (n - 1 - f) / F + 1) && !failed.load()) std::this_thread::yield();
+        if (failed.load()) return GSX_OK;
+        PreMultiArgs a{};
+        const int set = g % Ctx::kPreSets;
+        a.nv = std::min(F, n - g * F);
+        for (int v = 0; v < a.nv; ++v) {
+            const gsx_camera* cam = cams + (g * F + v);
+            Ctx::PreSet& ps = ctxs[v]->r_sets[set];
+            a.u[v] = view_uniforms(cam, W, H);
+            for (int k = 0; k < 3; ++k) a.cam[v][k] = (float)cam->p[k];
+            a.depth[v] = ps.depth.as<int>();
+            a.pre[v] = ps.pre.as<int>();
+            a.rec0[v] = ps.rec0.as<float4>();
+            a.rec1[v] = ps.rec1.as<float4>();
+            a.rec2[v] = ps.rec2.as<float2>();
+            a.rect[v] = ps.rect.as<uint32_t>();
+            GSX_HIP(c, hipMemcpyAsync(ps.pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
+        }
+        hipLaunchKernelGGL(pre_multi_kernel, dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(),
+                           (long long)c->rn, c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, a);
+        GSX_HIP(c, hipGetLastError());
+        GSX_HIP(c, hipEventRecord(c->r_pre_ev[set], c->stream));
+        pre_issued.store(g + 1, std::memory_order_release);
+        return GSX_OK;
+    };
     auto frames_of = [&](Ctx* t, int f) {
-        for (int k = f; k < n && rcs[f] == GSX_OK; k += F) {
+        int g = 0;
+        for (int k = f; k < n && rcs[f] == GSX_OK; k += F, ++g) {
+            if (multi) {
+                if (f == 0) {  // this thread: the pass of the NEXT group goes out before this group's frame (group 0's before the threads start)
+                    if (g + 1 < groups && (rcs[f] = issue_pre(g + 1))) break;
+                } else {
+                    while (pre_issued.load(std::memory_order_acquire) < g + 1 && !failed.load()) std::this_thread::yield();
+                    if (failed.load()) break;
+                    const hipError_t e = hipStreamWaitEvent(t->stream, c->r_pre_ev[g % Ctx::kPreSets], 0);
+                    if (e != hipSuccess) {
+                        rcs[f] = fail(t, GSX_E_HIP, "render_views: hipStreamWaitEvent: %s", hipGetErrorString(e));
+                        break;
+                    }
+                }
+                t->r_pre_ext = g % Ctx::kPreSets;
+            }
             rcs[f] = render_view(t, cams + k, W, H, rgba_out ? rgba_out[k] : nullptr);
+            t->r_pre_ext = -1;
             P[f] += t->r_P;
             used[f] += t->r_consumed;
+            done[f].store(g + 1, std::memory_order_release);
         }
+        t->r_pre_ext = -1;
+        if (rcs[f] != GSX_OK) failed.store(true);  // nobody waits for a pass or a frame that will not come
     };
+    if (multi && (rc = issue_pre(0))) return rc;
     std::thread others[Ctx::kMaxFrames - 1];
     int started = 0;
     try {
@@ -1026,12 +1226,14 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
                     frames_of(t, f);
                 } catch (...) {
                     rcs[f] = fail(t, GSX_E_INVALID, "render_views: a stream's host thread failed (out of host memory?)");
+                    failed.store(true);
                 }
             });
             ++started;
         }
         frames_of(c, 0);
     } catch (...) {
+        failed.store(true);
         for (int f = 0; f < started; ++f) others[f].join();  // never leave a joinable thread behind
         throw;
     }

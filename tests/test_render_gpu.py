@@ -171,13 +171,21 @@ def test_render_views_two_frames_in_flight(gsx):
             for cam in cams:
                 c.render_view(cam, W, H, to_host=False)
                 pairs += c.render_num_pairs()
-            for count in (7, 2, 1):
-                many = c.render_views(cams[:count], W, H)
-                assert many.shape == (count, H, W, 4)
-                for k in range(count):
-                    assert np.array_equal(many[k], single[k]), (n, deg, count, k)
-            c.render_views(cams, W, H, to_host=False)
-            assert c.render_num_pairs() == pairs
+            # round 3: with several frames in flight ONE pre pass per group of frames (pre_multi_kernel) reads the scene and its SH
+            # coefficients once for all of them; option render_multi_pre = 0 is round 2's form (every frame its own pass)
+            for frames, multi in ((4, 1), (4, 0), (2, 1), (3, 1), (6, 1), (1, 1)):
+                c.set_option("render_frames", frames)
+                c.set_option("render_multi_pre", multi)
+                for count in (7, 2, 1, 5):
+                    many = c.render_views(cams[:count], W, H)
+                    assert many.shape == (count, H, W, 4)
+                    for k in range(count):
+                        assert np.array_equal(many[k], single[k]), (n, deg, frames, multi, count, k)
+                c.render_views(cams, W, H, to_host=False)
+                assert c.render_num_pairs() == pairs
+                assert np.array_equal(c.render_view(cams[3], W, H), single[3])      # a single frame after a multi-frame call
+            c.set_option("render_frames", 4)
+            c.set_option("render_multi_pre", 1)
         assert c.render_views([], W, H, to_host=False) is None
 
 
