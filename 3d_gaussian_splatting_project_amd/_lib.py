@@ -93,6 +93,7 @@ _SIGS = {
     "gsx_vote_link_bytes": (C.c_int64, [C.c_void_p]),
     "gsx_vote_early_views": (C.c_int64, [C.c_void_p]),
     "gsx_vote_import": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gsx_vote_import_undo": (C.c_int, [C.c_void_p]),
     "gsx_vote_import_uniform": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.c_void_p, C.c_int64]),
     "gsx_vote_slab_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),

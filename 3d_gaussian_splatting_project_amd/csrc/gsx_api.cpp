@@ -181,6 +181,10 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         c->opt_render_phase_ratio = (int)value;
     }
     else if (k == "render_multi_pre") c->opt_render_multi_pre = value != 0;
+    else if (k == "render_share_stream") {
+        if ((value != 0) != (c->opt_render_share_stream != 0)) gsx::render_release_twin(c);  // the extra frames' streams are made anew
+        c->opt_render_share_stream = value != 0;
+    }
     else if (k == "render_frames") {
         if (value < 1 || value > Ctx::kMaxFrames) return gsx::fail(c, GSX_E_INVALID, "set_option: render_frames must be in [1,%d]", (int)Ctx::kMaxFrames);
         c->opt_render_frames = (int)value;
@@ -484,6 +488,10 @@ int gsx_vote_import_uniform(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_v
                             int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h, const void* pool_all_dev, int64_t pool_all_bytes) {
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_import_uniform(c, n_parts, part_views, part_offsets, cams, seg_w, seg_h, img_w, img_h, pool_all_dev, pool_all_bytes); });
+}
+int gsx_vote_import_undo(gsx_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    return gsx::guard(c, __func__, [&] { return gsx::vote_import_undo(c); });
 }
 int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size) {
     CTX_OR_FAIL(ctx);

@@ -212,6 +212,8 @@ struct Ctx {
     void* h_views = nullptr;   // pinned: view descriptors + culling planes on their way to d_views / d_cull
     size_t h_views_cap = 0;
     hipEvent_t h_views_ev = nullptr;
+    std::vector<ViewDesc> own_views;  // gsx_vote_import: this rank's own views, for gsx_vote_import_undo
+    int own_first_view = 0;
     const void* pool_base = nullptr;  // gsx_vote_import: the maps live in a caller-owned gathered pool, not in segpool
     int n_flushed = 0;         // views [0, n_flushed) are already in the planes
     bool planes_valid = false;  // planes hold votes (zeroed at begin/rewind)
@@ -235,6 +237,8 @@ struct Ctx {
     int early_done = 0;          // views [0, early_done) are in ecnt / efv (or, > 255 announced views, in the first early_batches planes of bcnt)
     int early_batches = 0;       // > 255 announced views: batches of labels_batched() whose count kernels already ran on stream2
     hipStream_t stream2 = nullptr;
+    bool stream_borrowed = false; // (a twin of gsx_render_views) `stream` is the parent context's second stream: not this context's to destroy
+    int opt_render_share_stream = 1;  // gsx_render_views: the first extra frame runs on the context's second stream instead of one more stream
     bool early_inflight = false; // early_done_ev was recorded on stream2 and c->stream has not been ordered behind it yet (early_join)
     hipEvent_t early_maps_ev = nullptr, early_done_ev = nullptr, early_up_ev = nullptr;
     DevBuf ecnt, efv;            // u8 [wave][bin][64]: counts / first-view codes of the early views
@@ -263,6 +267,7 @@ struct Ctx {
     };
     static constexpr int kPreSets = 3;
     PreSet r_sets[kPreSets];
+    DevBuf r_pre_args;                   // pre_multi_kernel's per-view arguments, one slot per record set
     hipEvent_t r_pre_ev[kPreSets] = {nullptr, nullptr, nullptr};  // recorded behind the pre pass that filled set s
     int r_pre_ext = -1;                  // >= 0: this frame's pre pass has been run for it into r_sets[r_pre_ext] (render_view skips its own)
     int opt_render_multi_pre = 1;        // gsx_render_views: one pre pass per group of frames in flight (0: every frame its own)
@@ -308,6 +313,7 @@ int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* p
                 const void* pool_all_dev, int64_t pool_all_bytes);
 int vote_import_uniform(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
                         int seg_w, int seg_h, int img_w, int img_h, const void* pool_all_dev, int64_t pool_all_bytes);
+int vote_import_undo(Ctx* c);
 int vote_slab_labels(Ctx* c, int slab, int slabs, int64_t* slab_size);
 int host_threads(Ctx* c);
 int vote_flush_pending(Ctx* c);  // queue the DMA of packed host maps that are still waiting for their group to fill
@@ -337,6 +343,7 @@ int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint3
                          const unsigned long long* n_dev, int bits, int* result_in);
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
+int second_stream(Ctx* c);
 int filter_check(Ctx* c, double* out);
 int kmeans(Ctx* c, int64_t n, const float* points, const float* colors, int k, const int64_t* init_index, int max_iter,
            double tol, int32_t* labels_out, float* centroids_out, int32_t* iterations_out, int32_t* converged_out);

@@ -433,11 +433,10 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
     depth_range_to(lo, hi, pre, slo, shi);
 }
 
-// The same for up to kPreViews views in ONE pass over the scene: a splat's texel pair and its SH coefficients (224 B at
-// degree 3) are read once and every view of the group gets its records from them - gsx_render_views keeps several frames in
-// flight, and each of them used to stream the whole scene again (4 x 816 MB at 3 M splats).  The coefficients are fetched
-// when the first view that draws the splat asks for a colour.  Per view the operations are pre_kernel's, on the same
-// operands: the frames are bit-identical.
+// The same for up to kPreViews views in ONE pass over the scene: a splat's texel pair is read once and its SH coefficients
+// (192 B at degree 3) come from HBM once - gsx_render_views keeps several frames in flight, and each of them used to stream
+// the whole scene again (4 x 816 MB at 3 M splats).  Per view the operations are pre_kernel's, on the same operands: the
+// frames are bit-identical.
 static constexpr int kPreViews = Ctx::kMaxFrames;
 struct PreMultiArgs {
     ViewUniforms u[kPreViews];
@@ -452,44 +451,39 @@ struct PreMultiArgs {
 };
 
 __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict__ tex, long long n, const float* __restrict__ sh_coef,
-                                                         int sh_deg, PreMultiArgs a) {
+                                                         int sh_deg, const PreMultiArgs* __restrict__ ap) {
+    // (the arguments live in device memory: indexed by the view they are scalar loads; passed by value the struct was
+    // promoted to 350 vector registers)
+    const PreMultiArgs& a = *ap;
     __shared__ int slo[4], shi[4];
-    int lo[kPreViews], hi[kPreViews];
-#pragma unroll
-    for (int v = 0; v < kPreViews; ++v) lo[v] = 2147483647, hi[v] = -2147483647 - 1;
-    const int K = (sh_deg + 1) * (sh_deg + 1);
+    // per-thread depth range of every view: thread-private columns of LDS (the view loop below is a REAL loop - unrolled six
+    // times the kernel needed 256 VGPRs and ran one wave per SIMD - so the ranges cannot sit in registers)
+    __shared__ int vlo[kPreViews][kRB], vhi[kPreViews][kRB];
+    const int nv = a.nv;
+    for (int v = 0; v < nv; ++v) vlo[v][threadIdx.x] = 2147483647, vhi[v][threadIdx.x] = -2147483647 - 1;
     for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
         const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
-        CoefRegs cf;
-        bool have = false;
-        auto fetch = [&] {
-            if (have) return;
-            have = true;
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < K) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) cf.v[3 * k + c] = sh_coef[((size_t)k * 3 + c) * (size_t)n + (size_t)i];
-                }
-        };
-#pragma unroll
-        for (int v = 0; v < kPreViews; ++v) {
-            if (v < a.nv) {  // wave-uniform
-                const PreOut o = pre_one(t0, t1, a.u[v], sh_coef != nullptr, sh_deg, a.cam[v][0], a.cam[v][1], a.cam[v][2], cf, fetch);
-                a.depth[v][i] = o.depth;
-                lo[v] = min(lo[v], o.depth);
-                hi[v] = max(hi[v], o.depth);
-                a.rec0[v][i] = o.r0;
-                a.rec1[v][i] = o.r1;
-                a.rec2[v][i] = o.r2;
-                a.rect[v][i] = o.rect;
-                if (i == 0) a.pre[v][2] = (int)o.rect;
-            }
+        // The SH coefficients are read through memory by every view that draws the splat (CoefMem, as in pre_kernel): the first
+        // view brings them in from HBM, the others find them in L2 a few hundred cycles later.  (Holding the 48 of them in
+        // registers across the views cost 48 VGPRs on top of the vertex shader's 60 and spilled.)
+#pragma unroll 1
+        for (int v = 0; v < nv; ++v) {  // wave-uniform: the view's uniforms come through scalar loads
+            long long ii = i;
+            asm volatile("" : "+v"(ii));  // (keeps the 48 coefficient addresses out of the loop's invariants: 96 VGPRs)
+            const CoefMem cf{sh_coef, n, ii};
+            const PreOut o = pre_one(t0, t1, a.u[v], sh_coef != nullptr, sh_deg, a.cam[v][0], a.cam[v][1], a.cam[v][2], cf, [] {});
+            a.depth[v][i] = o.depth;
+            vlo[v][threadIdx.x] = min(vlo[v][threadIdx.x], o.depth);
+            vhi[v][threadIdx.x] = max(vhi[v][threadIdx.x], o.depth);
+            a.rec0[v][i] = o.r0;
+            a.rec1[v][i] = o.r1;
+            a.rec2[v][i] = o.r2;
+            a.rect[v][i] = o.rect;
+            if (i == 0) a.pre[v][2] = (int)o.rect;
         }
     }
-#pragma unroll
-    for (int v = 0; v < kPreViews; ++v)
-        if (v < a.nv) depth_range_to(lo[v], hi[v], a.pre[v], slo, shi);
+#pragma unroll 1
+    for (int v = 0; v < nv; ++v) depth_range_to(vlo[v][threadIdx.x], vhi[v][threadIdx.x], a.pre[v], slo, shi);
 }
 
 // 16-bit depth bucket (gs.js:443-447) once the depth range is known; doubles as the (key, value) initialisation of the
@@ -1074,8 +1068,19 @@ static int twin_sync_scene(Ctx* c, int k) {
         c->twins[k] = new (std::nothrow) Ctx();
         if (!c->twins[k]) return fail(c, GSX_E_INVALID, "render_views: out of host memory");
         c->twins[k]->device = c->device;
-        hipError_t e = hipStreamCreateWithFlags(&c->twins[k]->stream, hipStreamNonBlocking);
+        hipError_t e = hipSuccess;
+        if (k == 0 && c->opt_render_share_stream) {
+            // the first extra frame runs on the context's second stream (the early vote's): with a stream of its own a process
+            // that has labelled before holds six streams for four hardware queues, and frames that share a queue serialise
+            // (bench.py's render leg: 1160-1200 views/s against 1335-1400 in a process that never labelled)
+            if (second_stream(c) != GSX_OK) e = hipErrorUnknown;
+            c->twins[k]->stream = c->stream2;
+            c->twins[k]->stream_borrowed = true;
+        } else {
+            e = hipStreamCreateWithFlags(&c->twins[k]->stream, hipStreamNonBlocking);
+        }
         if (e != hipSuccess) {
+            c->twins[k]->stream = nullptr;
             delete c->twins[k];
             c->twins[k] = nullptr;
             return fail(c, GSX_E_HIP, "render_views: hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -1111,7 +1116,8 @@ void render_release_twin(Ctx* c) {
             b->release();
         for (Ctx::PreSet& ps : t->r_sets)
             for (DevBuf* b : {&ps.depth, &ps.rect, &ps.rec0, &ps.rec1, &ps.rec2, &ps.pre}) b->release();
-        (void)hipStreamDestroy(t->stream);
+        if (!t->stream_borrowed) (void)hipStreamDestroy(t->stream);
+        t->stream = nullptr;
         delete t;
         t = nullptr;
     }
@@ -1157,6 +1163,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         for (int f = 0; f < F; ++f)
             for (Ctx::PreSet& ps : ctxs[f]->r_sets)
                 if ((rc = ensure_pre_set(c, ps, c->rn))) return rc;
+        GSX_HIP(c, c->r_pre_args.ensure(sizeof(PreMultiArgs) * Ctx::kPreSets));
         for (int s = 0; s < Ctx::kPreSets; ++s)
             if (!c->r_pre_ev[s]) GSX_HIP(c, hipEventCreateWithFlags(&c->r_pre_ev[s], hipEventDisableTiming));
     }
@@ -1181,8 +1188,10 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             a.rect[v] = ps.rect.as<uint32_t>();
             GSX_HIP(c, hipMemcpyAsync(ps.pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
         }
+        PreMultiArgs* a_dev = c->r_pre_args.as<PreMultiArgs>() + set;
+        GSX_HIP(c, hipMemcpyAsync(a_dev, &a, sizeof a, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
         hipLaunchKernelGGL(pre_multi_kernel, dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(),
-                           (long long)c->rn, c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, a);
+                           (long long)c->rn, c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, a_dev);
         GSX_HIP(c, hipGetLastError());
         GSX_HIP(c, hipEventRecord(c->r_pre_ev[set], c->stream));
         pre_issued.store(g + 1, std::memory_order_release);

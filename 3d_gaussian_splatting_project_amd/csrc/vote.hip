@@ -2363,14 +2363,23 @@ int early_join(Ctx* c) {
     return GSX_OK;
 }
 
-static int early_streams(Ctx* c) {
+// The context's SECOND stream: the early vote's, and the stream of the first extra frame of gsx_render_views (render.hip borrows
+// it: a context never labels and renders at the same time, and a process should not hold more streams than the hardware has
+// queues - two streams that share a queue serialise even when the GPU has room).
+int second_stream(Ctx* c) {
     if (c->stream2) return GSX_OK;
     // lowest priority: the kernels that expand the maps still arriving (c->stream) get the CUs the stage's waves free first
     int least = 0, greatest = 0;
     GSX_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
     GSX_HIP(c, hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, least));
-    GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
-    GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
+    return GSX_OK;
+}
+
+static int early_streams(Ctx* c) {
+    const int rc = second_stream(c);
+    if (rc) return rc;
+    if (!c->early_maps_ev) GSX_HIP(c, hipEventCreateWithFlags(&c->early_maps_ev, hipEventDisableTiming));
+    if (!c->early_done_ev) GSX_HIP(c, hipEventCreateWithFlags(&c->early_done_ev, hipEventDisableTiming));
     return GSX_OK;
 }
 
@@ -2904,6 +2913,34 @@ int vote_export(Ctx* c, int64_t reserve_bytes, void* blobs_out, void** pool_dev,
     return GSX_OK;
 }
 
+// The imported views replace the rank's own; those are kept aside so that gsx_vote_import_undo can put them back (a protocol
+// that imports optimistically and then learns that a peer's pool was not what the schedule assumed falls back to the plain
+// exchange, which starts from the rank's own views again).
+static void import_commit(Ctx* c, std::vector<ViewDesc>& all, const void* pool_all_dev) {
+    if (!c->pool_base) {  // (a second import on top of an import keeps the first one's saved state)
+        c->own_views.swap(c->views);
+        c->own_first_view = c->first_view;
+    }
+    c->views.swap(all);
+    c->views_dirty = true;
+    c->pool_base = pool_all_dev;
+    c->first_view = 0;
+    c->n_flushed = 0;
+    c->labels_valid = false;
+}
+
+int vote_import_undo(Ctx* c) {
+    if (!c->vote_begun || !c->pool_base) return fail(c, GSX_E_STATE, "vote_import_undo without a gsx_vote_import");
+    c->views.swap(c->own_views);
+    c->own_views.clear();
+    c->first_view = c->own_first_view;
+    c->pool_base = nullptr;
+    c->views_dirty = true;
+    c->n_flushed = 0;
+    c->labels_valid = false;
+    return GSX_OK;
+}
+
 int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* part_offsets, const void* blobs,
                 const void* pool_all_dev, int64_t pool_all_bytes) {
     if (!c->vote_begun) return fail(c, GSX_E_STATE, "vote_import before vote_begin");
@@ -2933,12 +2970,7 @@ int vote_import(Ctx* c, int n_parts, const int32_t* part_views, const int64_t* p
             d.hw32 = (float)d.half_w;  // (never trusted from the blob: the filter's proof needs exactly these)
             d.hh32 = (float)d.half_h;
         }
-    c->views.swap(all);
-    c->views_dirty = true;
-    c->pool_base = pool_all_dev;
-    c->first_view = 0;
-    c->n_flushed = 0;
-    c->labels_valid = false;
+    import_commit(c, all, pool_all_dev);
     return GSX_OK;
 }
 
@@ -2977,12 +3009,7 @@ int vote_import_uniform(Ctx* c, int n_parts, const int32_t* part_views, const in
             d.coarse_row_bytes = L.cstrip_bytes;
             d.coarse_delta = (unsigned)L.coarse_off;
         }
-    c->views.swap(all);
-    c->views_dirty = true;
-    c->pool_base = pool_all_dev;
-    c->first_view = 0;
-    c->n_flushed = 0;
-    c->labels_valid = false;
+    import_commit(c, all, pool_all_dev);
     return GSX_OK;
 }
 

@@ -365,6 +365,9 @@ class GpuGatherShard(_GpuShard):
     def import_uniform(self, part_views, part_offsets, cameras, map_size, image_size, pool_all):
         self.ctx.vote_import_uniform(part_views, part_offsets, cameras, map_size, image_size, pool_all.data_ptr(), pool_all.numel())
 
+    def undo_import(self):
+        self.ctx.vote_import_undo()
+
     def event(self):
         """a timing event recorded on the ctx stream (torch's current stream must be the ctx stream: `with shard.stream()`)"""
         e = torch.cuda.Event(enable_timing=True)
@@ -418,6 +421,9 @@ class HostGatherShard:
 
     def import_uniform(self, part_views, part_offsets, cameras, map_size, image_size, pool_all):
         self.shard.import_uniform(part_views, part_offsets, cameras, map_size, image_size, pool_all.numpy())
+
+    def undo_import(self):
+        self.shard.views = None
 
     def slab_labels(self, rank, world):
         return torch.from_numpy(self.shard.slab_labels(rank, world))
@@ -679,6 +685,8 @@ class GatherPipeline:
             fw.wait()
         ok = bool(self.stride) and bool(flags.cpu().numpy().all())
         if not ok:                                          # every rank sees the same flags: all take the plain path together
+            if self.stride:
+                shard.undo_import()                         # ... from their own views again
             return exchange_labels_gather(shard, self.group, to_host, out, cap_views=max(1, self.total))
         self._phases(events, t_fin)
         return res

@@ -321,6 +321,9 @@ class Context:
                                                 int(map_size[0]), int(map_size[1]), int(image_size[0]), int(image_size[1]),
                                                 C.c_void_p(pool_all_ptr), int(pool_all_bytes)), self.h)
 
+    def vote_import_undo(self):
+        check(self._lib.gsx_vote_import_undo(self.h), self.h)
+
     def vote_slab_labels(self, slab, slabs):
         """-> slab size S; the slab's labels (Morton order) are the first S words at keys_device()."""
         sn = C.c_int64()

@@ -301,6 +301,9 @@ int gsx_vote_import(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, co
  * all ranks must run the same build with the same options).  No exchange of view blobs is needed then. */
 int gsx_vote_import_uniform(gsx_ctx* ctx, int32_t n_parts, const int32_t* part_views, const int64_t* part_offsets, const gsx_camera* cams,
                             int32_t seg_w, int32_t seg_h, int32_t img_w, int32_t img_h, const void* pool_all_dev, int64_t pool_all_bytes);
+/* takes the last gsx_vote_import / gsx_vote_import_uniform back: the context holds this rank's own views in its own pool again
+ * (a protocol that imports before it knows whether every rank's pool was what the schedule assumed can fall back) */
+int gsx_vote_import_undo(gsx_ctx* ctx);
 /* votes the Gaussians [slab * S, min(n, (slab+1) * S)) of the Morton order over all staged views, S = *slab_size =
  * ceil(n / slabs) rounded up to 256; labels (int32, Morton order) at gsx_vote_keys_device()[0 .. S). */
 int gsx_vote_slab_labels(gsx_ctx* ctx, int32_t slab, int32_t slabs, int64_t* slab_size);

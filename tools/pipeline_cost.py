@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""GPU box: host-side cost of the pipelined gather, one-rank RCCL group (collectives run for real on this rank alone)."""
+"""GPU box: host-side cost of the pipelined gather, one-rank RCCL group (collectives run for real on this rank alone):
+one rank's 25-view share of configs[3] through the single-GPU vote, the plain gather, round 2's pipeline (header exchange with
+the view blobs) and round 3's (every rank derives the descriptors from the shared camera list: "local")."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +16,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 n, V, W, H = 3_000_000, 25, 1920, 1080          # one rank's share of configs[3] at 8 GPUs
 pos = scene.make_positions(n, scene.BASE_SEED + 3)
 cams = [pkg.Camera.from_dict(c) for c in scene.make_cameras(200, W, H, convention="w2c")[:V]]
+cam_arr = pkg.camera_array(cams)
 segs = [scene.make_segmap(H, W, 150, 3000 + v, cell=4) for v in range(V)]
 ctx = pkg.Context(0)
 ctx.upload_positions(pos)
@@ -21,8 +24,9 @@ out = np.empty(n, np.int32)
 shard = pkg.dist.GpuGatherShard(ctx)
 def run(mode, chunks=4):
     ctx.vote_begin(150, 0, V)
-    if mode == "pipe":
-        p = pkg.dist.GatherPipeline(shard, V, chunks=chunks, assume_uniform=True)
+    if mode in ("pipe", "local"):
+        kw = dict(cameras=cam_arr, map_size=(W, H)) if mode == "local" else dict(assume_uniform=True)
+        p = pkg.dist.GatherPipeline(shard, V, chunks=chunks, **kw)
         for v in range(V):
             ctx.vote_view(cams[v], segs[v]); p.after_view()
         p.finish(out=out)
@@ -34,7 +38,7 @@ def run(mode, chunks=4):
         for v in range(V):
             ctx.vote_view(cams[v], segs[v])
         ctx.vote_finalize(out=out)
-for mode, ch in (("single", 0), ("gather", 0), ("pipe", 1), ("pipe", 2), ("pipe", 4), ("pipe", 8)):
+for mode, ch in (("single", 0), ("gather", 0), ("pipe", 1), ("pipe", 4), ("local", 1), ("local", 2), ("local", 4), ("local", 8), ("pipe", 4), ("local", 4)):
     for _ in range(3): run(mode, ch)
     t0 = time.perf_counter()
     for _ in range(20): run(mode, ch)

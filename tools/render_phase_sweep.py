@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""GPU box: views/s of gsx_render_views (four frames in flight) by the depth-phase options (render_phases, render_phase_ratio,
+exact_cull, tile_lpt), bench scene (3 M splats / 1080p / SH 3); pairs sorted / consumed per view alongside."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+scene = pkg.scene
+n, W, H = 3_000_000, 1920, 1080
+seed = scene.BASE_SEED + 3
+xyz = scene.make_positions(n, seed)
+a = scene.make_splat_attributes(n, seed, sh_degree=3)
+cams = scene.make_cameras(24, W, H, convention="c2w")
+with pkg.Context(0) as c:
+    c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+    c.upload_sh(a["f_rest"], 3)
+    for opts in ({}, {"render_phases": 3}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 2, "render_phase_ratio": 8},
+                 {"render_phases": 2, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 3}, {"exact_cull": 1},
+                 {"render_phases": 3, "exact_cull": 1}, {"tile_lpt": 0}, {}):
+        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 1}
+        base.update(opts)
+        for k, v in base.items():
+            c.set_option(k, v)
+        c.render_views(cams, W, H, to_host=False)
+        t0 = time.perf_counter()
+        for rep in range(3):
+            c.render_views(cams, W, H, to_host=False)
+        dt = (time.perf_counter() - t0) / (3 * len(cams))
+        print(f"{opts}: {dt * 1e3:.3f} ms/view = {1 / dt:.0f} views/s   pairs sorted {c.render_num_pairs() // len(cams)}  consumed {c.render_num_pairs_consumed() // len(cams)}", flush=True)
