@@ -31,6 +31,7 @@ with gsx.Context(0) as c:
         opts = {"spatial_sort": int(rng.random() < 0.8), "seg_tiled": int(rng.random() < 0.9), "vote_unroll": int(rng.choice([2, 4, 8])),
                 "flat_project": int(rng.random() < 0.85), "wave_cull": int(rng.random() < 0.8), "seg_coarse": int(rng.random() < 0.8),
                 "xcd_swizzle": int(rng.choice([0, 1, 4, 32])), "fast_div": int(rng.random() < 0.3), "lds_batch": int(rng.random() < 0.2)}
+        opts["filter_project"] = int(rng.random() < 0.8)
         opts["host_threads"] = int(rng.choice([1, 3, 16]))
         opts["labels_u8"] = int(rng.random() < 0.8)
         opts["host_compact"] = int(rng.random() < 0.7)
@@ -100,7 +101,13 @@ with gsx.Context(0) as c:
             pool = dist.device_bytes_tensor(ptr, max(used, 256), 0).clone()
             cuts = sorted(set([0, V] + [int(x) for x in rng.integers(0, V + 1, size=2)]))
             parts = [b - a for a, b in zip(cuts, cuts[1:])]
-            c.vote_import(parts, [0] * len(parts), blobs, pool.data_ptr(), pool.numel())
+            uniform = all(sz == sizes[0] for sz in sizes) and all(s_.shape == segs[0].shape for s_ in segs)
+            if uniform and rng.random() < 0.6:    # round 3: the descriptors derived from the camera list instead of the blobs
+                stride = used // V
+                assert stride * V == used and stride % 256 == 0
+                c.vote_import_uniform(parts, [a * stride for a in cuts[:-1]], cams, segs[0].shape[::-1], sizes[0], pool.data_ptr(), pool.numel())
+            else:
+                c.vote_import(parts, [0] * len(parts), blobs, pool.data_ptr(), pool.numel())
             slabs = []
             for r_ in range(world):
                 sn = c.vote_slab_labels(r_, world)
@@ -110,6 +117,9 @@ with gsx.Context(0) as c:
             full = torch.cat(slabs)
             torch.cuda.synchronize()
             assert np.array_equal(c.vote_labels_from_sorted(full.data_ptr()), want), ("slab votes", seed, trial, n, V, C, world, opts)
+            if rng.random() < 0.5:                # the import taken back: the context votes its own views in its own pool again
+                c.vote_import_undo()
+                assert np.array_equal(c.vote_finalize(), want), ("import undone", seed, trial, n, V, C, opts)
         if trial % 20 == 0:
             print(f"trial {trial}/{trials} ok  ({time.time() - t0:.0f} s, {culled_total} wave-views culled so far)", flush=True)
 print(f"SOAK OK: seed {seed}, {trials} trials, {culled_total} wave-views culled, {time.time() - t0:.0f} s")
