@@ -201,7 +201,6 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "batched_counts") c->opt_batched_counts = value != 0;
     else if (k == "wave_cull") c->opt_wave_cull = value != 0;
     else if (k == "filter_project") c->opt_filter_project = value != 0;
-    else if (k == "lds_wave_layout") c->opt_lds_wave_layout = value != 0;
     else if (k == "host_pack") c->opt_host_pack = value != 0;
     else if (k == "labels_u8") c->opt_labels_u8 = value != 0;
     else if (k == "host_compact") c->opt_host_compact = value != 0;

@@ -227,12 +227,11 @@ struct Ctx {
     bool labels_valid = false;
     // early vote (vote.hip: early_vote_stage): the views [0, early_done) are voted on a second stream while the host is
     // still handing over the rest of the run; vote_finalize then only walks the views behind them
-    int opt_lds_wave_layout = 0; // one-piece vote kernel: a wave's histograms as [bin][64 lanes] bytes (the last stage's layout) instead of a row per thread
     int opt_filter_project = 1;  // fp32 filter in front of the two fp64 divisions of the projection (vote.hip: project_filtered); exact by construction
     int opt_early_vote = 1;      // 0: off, 1: for runs worth it (one rank holds all <= 255 views, a large scene), 2: whenever possible (tests)
     int opt_early_at = 0;        // the stage starts when this many permille of the announced views are staged; 0: chosen from the run's own hand-over rate
     std::chrono::steady_clock::time_point early_t0;  // first gsx_vote_view of the run
-    int opt_early_replay = 0;    // 1: the early stage only records the votes, the last stage replays them (vote_record_kernel / vote_fused_replay_kernel)
+    int opt_early_replay = 1;    // 1 (default since round 3): the early stage only records the votes, the last stage replays them (vote_record_kernel / vote_fused_replay_kernel); 0: count + first-view planes and the fold
     bool early_replayed = false; // this run's early stage was a record-only one
     int early_state = 0;         // 0: not started in this run, 1: started, -1: not available any more (rewind, pool moved)
     int early_done = 0;          // views [0, early_done) are in ecnt / efv (or, > 255 announced views, in the first early_batches planes of bcnt)

@@ -770,19 +770,16 @@ __device__ __forceinline__ void gather_chunk(const ViewDesc* __restrict__ views,
     }
 }
 
-// WL: the histogram of a wave as [bin][64 lanes] bytes (the last stage's layout: lanes voting one bin touch 16 consecutive
-// dwords) instead of one row of `stride_dw` dwords per thread; p.stride_dw then holds the rows per wave, (bins + 3) / 4.
-template <int U, int DIV, bool LDS_BATCH, bool WL = false>
+// (The last stage's LDS layout - a wave's histograms as [bin][64 lanes] bytes - was measured here too, round 3: 1.052 ms against
+// 1.036-1.043 for the row per thread, profiles/r03/lds_layout_and_replay_ab.txt; removed again.)
+template <int U, int DIV, bool LDS_BATCH>
 __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p, const ViewDesc* __restrict__ views,
                                                                    int* __restrict__ labels) {
     extern __shared__ uint32_t lds[];
-    constexpr int HS = WL ? 64 : 1;  // byte stride between a lane's counters of consecutive bins
-    uint32_t* row = WL ? lds + (threadIdx.x >> 6) * (p.stride_dw * 64) + (threadIdx.x & 63) : lds + threadIdx.x * p.stride_dw;
-    uint8_t* h = WL ? reinterpret_cast<uint8_t*>(lds + (threadIdx.x >> 6) * (p.stride_dw * 64)) + (threadIdx.x & 63)
-                    : reinterpret_cast<uint8_t*>(row);
+    uint32_t* row = lds + threadIdx.x * p.stride_dw;
+    uint8_t* h = reinterpret_cast<uint8_t*>(row);
 
-    for (int k = 0; k < p.stride_dw; ++k) row[WL ? k * 64 : k] = 0;  // WL: the wave's block, dword lane + 64 k; else thread-private
-    if (WL) __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < p.stride_dw; ++k) row[k] = 0;  // thread-private: no barrier needed
     const long long i = (long long)logical_block(blockIdx.x, gridDim.x, p.xcd_swizzle) * kBlock + threadIdx.x;
     const bool valid = i < p.n;
     // lanes past the end carry NaN: every comparison in project() fails, they never vote
@@ -809,14 +806,14 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
             // inside the chunk in registers, then apply the votes in (reverse view) order
             int old[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (int)h[bin[u] * HS] : 0;
+            for (int u = 0; u < U; ++u) old[u] = bin[u] >= 0 ? (int)h[bin[u]] : 0;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (bin[u] >= 0) {
                     int c = old[u] + 1;  // dls.py:295
 #pragma unroll
                     for (int w = 0; w < u; ++w) c += (bin[w] == bin[u]) ? 1 : 0;
-                    h[bin[u] * HS] = (uint8_t)c;  // LDS stores of one wave retire in order: the last repeat wins
+                    h[bin[u]] = (uint8_t)c;  // LDS stores of one wave retire in order: the last repeat wins
                     if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
                         bestc = c;
                         best = bin[u];
@@ -827,8 +824,8 @@ __global__ __launch_bounds__(kBlock) void vote_fused_labels_kernel(FusedParams p
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (bin[u] >= 0) {
-                    const int c = h[bin[u] * HS] + 1;  // dls.py:295
-                    h[bin[u] * HS] = (uint8_t)c;
+                    const int c = h[bin[u]] + 1;  // dls.py:295
+                    h[bin[u]] = (uint8_t)c;
                     if (c >= bestc) {  // reverse-order tie rule == first-inserted wins (dls.py:303)
                         bestc = c;
                         best = bin[u];
@@ -2770,16 +2767,10 @@ static int labels_one_batch(Ctx* c, const VoteRange& r, const uint32_t* perm, in
     static const K table[3][kDivModes][2] = {GSX_ROW(2), GSX_ROW(4), GSX_ROW(8)};
 #undef GSX_ROW
     K k = table[ui][div_mode(c)][c->opt_lds_batch ? 1 : 0];
-    size_t lds_bytes = lds;
-    if (c->opt_lds_wave_layout && ui == 2 && !c->opt_lds_batch && div_mode(c) == kDivFiltCoarse) {  // experiment: [bin][64] per wave
-        k = vote_fused_labels_kernel<8, kDivFiltCoarse, false, true>;
-        p.stride_dw = (c->bins + 3) / 4;
-        lds_bytes = (size_t)(kBlock / 64) * p.stride_dw * 256;
-    }
-    int rc = set_lds(c, k, lds_bytes);
+    int rc = set_lds(c, k, lds);
     if (rc) return rc;
     ProfScope ps(c, "vote_fused_labels");
-    hipLaunchKernelGGL(k, dim3(grid_for(r.n)), dim3(kBlock), lds_bytes, c->stream, p, p.views, out);
+    hipLaunchKernelGGL(k, dim3(grid_for(r.n)), dim3(kBlock), lds, c->stream, p, p.views, out);
     GSX_HIP(c, hipGetLastError());
     return GSX_OK;
 }

@@ -110,9 +110,11 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               the run's size (tests).  "early_vote_at": the stage starts when this many permille of the
  *                               announced views are staged; 0 (default): chosen from the run's own hand-over rate so
  *                               that the stage ends as the last map arrives (between 50 and 88 %)
- *   "early_replay" (default 0)  the other form of the early vote: the early stage only RECORDS every vote (no histogram,
- *                               0.9 GB less memory at 3 M Gaussians), the last stage replays the record behind its own
- *                               walk in the one-piece kernel's order.  Same labels; measured within 0.03 ms of the default
+ *   "early_replay" (default 1)  the form of the early vote: 1 = the early stage only RECORDS every vote (no histogram, no LDS:
+ *                               0.73 ms of GPU time for 160 of 200 views at 3 M Gaussians), the last stage replays the record
+ *                               behind its own walk in the one-piece kernel's order; 0 = the early stage keeps count and
+ *                               first-view planes (1.85 ms, 0.9 GB more memory) and the last stage folds them in.  Same
+ *                               labels, same span within the run-to-run spread (round 3 made the cheaper one the default)
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce

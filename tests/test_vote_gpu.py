@@ -297,10 +297,13 @@ def test_early_vote_matches_reference_golden(gsx, case, replay):
             assert _kernel_launches(c, last) == finals
 
 
-def test_early_vote_on_a_large_scene(gsx):
+@pytest.mark.parametrize("replay", [1, 0], ids=["replay", "planes"])
+def test_early_vote_on_a_large_scene(gsx, replay):
     """The automatic form (early_vote = 1: large scene, >= 32 views, all on this rank): random labels per pixel make most
     Gaussians tied between several bins, so the first-view plane decides; ragged N; views that see nothing; a caller that
-    stops before the announced number of views; maps of two geometries (no coarse level for one)."""
+    stops before the announced number of views; maps of two geometries (no coarse level for one).  Both forms of the early vote:
+    record + replay (the default since round 3) and planes + fold."""
+    last = "vote_fused_replay" if replay else "vote_fused_final"
     n, V, W, H = 300_007, 40, 320, 180
     pos, cams, segs = scene.make_scene(n, V, W, H, config_id=7, convention="w2c")
     rng = np.random.default_rng(5)
@@ -311,10 +314,11 @@ def test_early_vote_on_a_large_scene(gsx):
     want = oracle.assign_labels(pos, cams, segs, sizes, threads=0)
     assert (want != -1).mean() > 0.5
     with gsx.Context(0) as c:
+        c.set_option("early_replay", replay)
         c.profile(True)
         got = run_gpu(c, pos, cams, segs, sizes).vote_finalize()      # split point chosen from the hand-over rate
         assert np.array_equal(got, want)
-        assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 0
+        assert _kernel_launches(c, last) == 1 and _kernel_launches(c, "vote_fused_labels") == 0
         assert V // 2 <= c.vote_early_views() <= V * 88 // 100
         c.set_option("early_vote_at", 700)
         assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want) and c.vote_early_views() == 28
@@ -322,7 +326,7 @@ def test_early_vote_on_a_large_scene(gsx):
         assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want)
         c.set_option("early_vote", 0)
         assert np.array_equal(run_gpu(c, pos, cams, segs, sizes).vote_finalize(), want)
-        assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_fused_labels") == 1
+        assert _kernel_launches(c, last) == 1 and _kernel_launches(c, "vote_fused_labels") == 1
         c.set_option("early_vote", 1)
         # 40 views announced, 33 handed over: the stage ran after 28, the last stage takes the 5 that came
         want33 = oracle.assign_labels(pos, cams[:33], segs[:33], sizes[:33], threads=0)
@@ -331,13 +335,13 @@ def test_early_vote_on_a_large_scene(gsx):
         for v in range(33):
             c.vote_view(cams[v], segs[v], sizes[v])
         assert np.array_equal(c.vote_finalize(), want33)
-        assert _kernel_launches(c, "vote_fused_final") == 2
+        assert _kernel_launches(c, last) == 2
         # exactly the early views and nothing behind them
         c.vote_begin(150, 0, V)
         for v in range(28):
             c.vote_view(cams[v], segs[v], sizes[v])
         assert np.array_equal(c.vote_finalize(), oracle.assign_labels(pos, cams[:28], segs[:28], sizes[:28], threads=0))
-        assert _kernel_launches(c, "vote_fused_final") == 3
+        assert _kernel_launches(c, last) == 3
         # a second geometry after the stage (the pool has room: no move), scaled lookups in the last stage
         segs2 = list(segs)
         sizes2 = list(sizes)
@@ -351,6 +355,7 @@ def test_early_vote_on_a_large_scene(gsx):
             segs3[v] = rng.integers(-1, 150, size=(H * 4, W * 4)).astype(np.int32)
         want3 = oracle.assign_labels(pos, cams, segs3, sizes, threads=0)
         with gsx.Context(0) as c2:
+            c2.set_option("early_replay", replay)
             assert np.array_equal(run_gpu(c2, pos, cams, segs3, sizes).vote_finalize(), want3)
 
 
@@ -1012,7 +1017,7 @@ def test_full_size_properties(gsx):
     mixed = np.mean([(s[:H // 4 * 4:4, :W // 4 * 4:4] != s[3:H // 4 * 4:4, 3:W // 4 * 4:4]).mean() for s in segs[:5]])
     assert mixed > 0.05                                    # (a lower bound on the mixed cells: corner pixels differ)
     got = {}
-    for name, opts in (("planes", {}), ("replay", {"early_replay": 1}), ("one piece", {"early_vote": 0})):
+    for name, opts in (("planes", {"early_replay": 0}), ("replay", {}), ("one piece", {"early_vote": 0})):
         with gsx.Context(0) as c:
             for k, v in opts.items():
                 c.set_option(k, v)
@@ -1025,6 +1030,8 @@ def test_full_size_properties(gsx):
             early = c.vote_early_views()
             assert (early >= V // 2) == (name != "one piece"), (name, early)
             assert _kernel_launches(c, "seg_expand") > 0 and c.vote_link_bytes() < 0.4 * V * W * H   # compact records crossed the link
+            if name == "replay":            # the default form since round 3
+                assert _kernel_launches(c, "vote_fused_replay") == 1 and _kernel_launches(c, "vote_early_record") == 1
             if name == "planes":
                 assert _kernel_launches(c, "vote_fused_final") == 1 and _kernel_launches(c, "vote_early_planes") == 1
                 c.vote_rewind()

@@ -18,7 +18,8 @@ KERNELS = {"vote_fused_labels": "vote_fused_labels_kernel", "seg_pack_fused": "s
            "radix_scatter": "radix_scatter_kernel", "radix_hist": "radix_hist_kernel", "pre": "pre_kernel", "bin_count": "bin_kernel<false>",
            "bin_emit": "bin_kernel<true>", "ranges": "ranges_kernel", "bucket": "bucket_kernel", "unpermute": "unpermute_labels_kernel",
            "seg_expand": "seg_expand_kernel", "labels_narrow": "labels_narrow_kernel",
-           "vote_early_planes": "vote_fused_planes_kernel", "vote_fused_final": "vote_fused_final_kernel"}
+           "vote_early_planes": "vote_fused_planes_kernel", "vote_fused_final": "vote_fused_final_kernel",
+           "vote_early_record": "vote_record_kernel", "vote_fused_replay": "vote_fused_replay_kernel", "pre_multi": "pre_multi_kernel"}
 
 
 def one(pattern):

@@ -68,7 +68,7 @@ except Exception as e:   # an older summary without the stamp files
     stamp["error"] = str(e)
 cached = {"_stamp": stamp, "_comment": f"PMC figures of profiles/{rnd}/counters_by_kernel_{tag}.json (rocprofv3, separate --pmc passes; derivations in "
                       "tools/summarize_profiles.py).  bench.py quotes them as CACHED profile figures next to its live timings."}
-for name in ("vote_fused_labels", "vote_early_planes", "vote_fused_final"):
+for name in ("vote_fused_labels", "vote_early_planes", "vote_fused_final", "vote_early_record", "vote_fused_replay"):
     v = derived.get(name)
     if not v:
         continue
