@@ -438,6 +438,11 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
 // the whole scene again (4 x 816 MB at 3 M splats).  Per view the operations are pre_kernel's, on the same operands: the
 // frames are bit-identical.
 static constexpr int kPreViews = Ctx::kMaxFrames;
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* p, const float4 v) {
+    nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
 struct PreMultiArgs {
     ViewUniforms u[kPreViews];
     float cam[kPreViews][3];
@@ -472,13 +477,16 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
             asm volatile("" : "+v"(ii));  // (keeps the 48 coefficient addresses out of the loop's invariants: 96 VGPRs)
             const CoefMem cf{sh_coef, n, ii};
             const PreOut o = pre_one(t0, t1, a.u[v], sh_coef != nullptr, sh_deg, a.cam[v][0], a.cam[v][1], a.cam[v][2], cf, [] {});
-            a.depth[v][i] = o.depth;
+            // streaming stores: the records are not read again by this kernel, and written the ordinary way they push the
+            // splat's coefficients out of the 4 MB L2 before the next view of this loop asks for them again
+            __builtin_nontemporal_store(o.depth, &a.depth[v][i]);
             vlo[v][threadIdx.x] = min(vlo[v][threadIdx.x], o.depth);
             vhi[v][threadIdx.x] = max(vhi[v][threadIdx.x], o.depth);
-            a.rec0[v][i] = o.r0;
-            a.rec1[v][i] = o.r1;
-            a.rec2[v][i] = o.r2;
-            a.rect[v][i] = o.rect;
+            nt_store4(&a.rec0[v][i], o.r0);
+            nt_store4(&a.rec1[v][i], o.r1);
+            __builtin_nontemporal_store(o.r2.x, &a.rec2[v][i].x);
+            __builtin_nontemporal_store(o.r2.y, &a.rec2[v][i].y);
+            __builtin_nontemporal_store(o.rect, &a.rect[v][i]);
             if (i == 0) a.pre[v][2] = (int)o.rect;
         }
     }

@@ -371,8 +371,10 @@ def main():
                     st = allc.get("_stamp", {})
                     if st.get("vote_hip_sha16") != sha:
                         stale = f"profiles/counters.json was taken on another build of csrc/vote.hip ({st.get('vote_hip_sha16')} != {sha})"
-                    elif name != "vote_fused_labels" and abs((st.get("early_views") or -99) - int(early_views)) > 4:
+                    elif name != "vote_fused_labels" and abs((st.get("early_views") or -99) - int(early_views)) > 0.15 * total_views:
                         stale = f"profiles/counters.json was taken with {st.get('early_views')} early views, this run chose {int(early_views)}"
+                    elif name != "vote_fused_labels":
+                        cached = dict(cached, source=f"{cached.get('source')} (taken with {st.get('early_views')} early views under the profiler; this run: {int(early_views)})")
                 except Exception:
                     cached = {}
             if stale:

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""GPU box: gsx_render_views on the bench scene (3 M splats / 1080p / SH 3), 24 views x argv[1] calls - the program rocprofv3 passes
+of the rasterizer wrap (tools/gpu_r03_pre_pmc.sh)."""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+scene = pkg.scene
+n, W, H = 3_000_000, 1920, 1080
+seed = scene.BASE_SEED + 3
+xyz = scene.make_positions(n, seed)
+a = scene.make_splat_attributes(n, seed, sh_degree=3)
+cams = scene.make_cameras(24, W, H, convention="c2w")
+with pkg.Context(0) as c:
+    c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+    c.upload_sh(a["f_rest"], 3)
+    for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
+        c.render_views(cams, W, H, to_host=False)
