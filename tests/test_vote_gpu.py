@@ -1148,6 +1148,7 @@ def test_randomised_small_configurations(gsx):
             c.set_option("seg_coarse", int(rng.integers(0, 2)))
             c.set_option("early_vote", int(rng.choice([0, 2])))
             c.set_option("early_replay", int(rng.integers(0, 2)))
+            c.set_option("filter_project", int(rng.integers(0, 2)))
             c.set_option("early_vote_at", int(rng.integers(1, 1001)))
             pos = (rng.normal(size=(n, 3)) * rng.choice([0.5, 2.0, 6.0])).astype(np.float32)
             cams, segs, sizes = [], [], []
