@@ -758,6 +758,45 @@ def test_gather_exchange_on_one_gpu(gsx):
                     c.close()
 
 
+def test_import_uniform_and_undo(gsx):
+    """gsx_vote_import_uniform: the descriptors of all views derived from the camera list (round 3's multi-GPU protocol) give the
+    labels of gsx_vote_import's blobs; gsx_vote_import_undo puts the context's own views back; bad arguments are errors, not
+    out-of-bounds reads."""
+    import torch
+    n, V, W, H = 30_000, 7, 320, 180
+    pos, cams, segs = scene.make_scene(n, V, W, H, config_id=17, convention="w2c")
+    want = oracle.assign_labels(pos, cams, segs, [(W, H)] * V, threads=0)
+    with gsx.Context(0) as c:
+        run_gpu(c, pos, cams, segs, [(W, H)] * V)
+        ptr, used, blobs = c.vote_export(0)
+        stride = used // V
+        pool = gsx.dist.device_bytes_tensor(ptr, used, 0).clone()
+        with pytest.raises(gsx.GsxError):
+            c.vote_import_undo()                                               # nothing imported yet
+        for parts, offs in (([V], [0]), ([3, 4], [0, 3 * stride]), ([1, 0, 6], [0, stride, stride])):
+            c.vote_import_uniform(parts, offs, cams, (W, H), (W, H), pool.data_ptr(), pool.numel())
+            slabs = []
+            for r in range(2):
+                sn = c.vote_slab_labels(r, 2)
+                kp, _ = c.keys_device()
+                c.synchronize()
+                slabs.append(gsx.dist.device_words_tensor(kp, sn, 0).clone())
+            full = torch.cat(slabs)
+            torch.cuda.synchronize()
+            assert np.array_equal(c.vote_labels_from_sorted(full.data_ptr()), want), parts
+            with pytest.raises(gsx.GsxError):
+                c.vote_view(cams[0], segs[0])                                  # the run's views are final after an import
+            c.vote_import_undo()
+            assert c.vote_num_views() == V and np.array_equal(c.vote_finalize(), want)
+        with pytest.raises(ValueError):
+            c.vote_import_uniform([V], [stride], cams, (W, H), (W, H), pool.data_ptr(), pool.numel())     # the last view would end outside the pool
+        with pytest.raises(ValueError):
+            c.vote_import_uniform([V], [-1], cams, (W, H), (W, H), pool.data_ptr(), pool.numel())
+        with pytest.raises(ValueError):
+            c.vote_import_uniform([V], [0], cams, (0, H), (W, H), pool.data_ptr(), pool.numel())
+        assert np.array_equal(c.vote_finalize(), want)                        # failed imports left the context alone
+
+
 def test_seg_dtypes_and_device_maps(ctx):
     """Every dtype a segmentation map can arrive in gives the labels of its int32 form (the reference indexes its vote
     dict with the array values whatever the dtype, dls.py:288-295): int64 (SegFormer argmax), int16, uint8 class
