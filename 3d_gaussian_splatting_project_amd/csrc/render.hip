@@ -1198,7 +1198,12 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         }
         PreMultiArgs* a_dev = c->r_pre_args.as<PreMultiArgs>() + set;
         GSX_HIP(c, hipMemcpyAsync(a_dev, &a, sizeof a, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
-        hipLaunchKernelGGL(pre_multi_kernel, dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(),
+        // opt_render_pre_lds: bytes of LDS the launch asks for and never touches - it caps the workgroups resident per CU, i.e. the
+        // bytes of coefficients in flight between a splat's first view and its next ones, which must fit the 4 MB L2 of an XCD
+        if (c->opt_render_pre_lds > 0)
+            GSX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pre_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           c->opt_render_pre_lds));
+        hipLaunchKernelGGL(pre_multi_kernel, dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), (size_t)std::max(0, c->opt_render_pre_lds), c->stream, c->r_tex.as<uint4>(),
                            (long long)c->rn, c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, a_dev);
         GSX_HIP(c, hipGetLastError());
         GSX_HIP(c, hipEventRecord(c->r_pre_ev[set], c->stream));

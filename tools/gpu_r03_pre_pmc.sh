@@ -4,9 +4,9 @@
 set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/pre_pmc; rm -rf $OUT; mkdir -p $OUT $ROOT/gpurun_out/r03
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/render_views_loop.py 2 > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/tools/render_views_loop.py 1 > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/tools/render_views_loop.py 1 > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/tools/render_views_loop.py 2 $PRE_OPTS > $OUT/stats.log 2>&1 || { tail -5 $OUT/stats.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/tools/render_views_loop.py 1 $PRE_OPTS > $OUT/fetch.log 2>&1 || { tail -5 $OUT/fetch.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ROOT/tools/render_views_loop.py 1 $PRE_OPTS > $OUT/write.log 2>&1 || { tail -5 $OUT/write.log; exit 1; }
 python3 - <<PY | tee $ROOT/gpurun_out/r03/pre_pmc.txt
 import csv, glob, collections
 out = "$OUT"

@@ -12,6 +12,9 @@ xyz = scene.make_positions(n, seed)
 a = scene.make_splat_attributes(n, seed, sh_degree=3)
 cams = scene.make_cameras(24, W, H, convention="c2w")
 with pkg.Context(0) as c:
+    for kv in sys.argv[2:]:
+        k, v = kv.split("=")
+        c.set_option(k, int(v))
     c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
     c.upload_sh(a["f_rest"], 3)
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
