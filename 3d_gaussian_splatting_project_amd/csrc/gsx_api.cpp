@@ -181,10 +181,6 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
         c->opt_render_phase_ratio = (int)value;
     }
     else if (k == "render_multi_pre") c->opt_render_multi_pre = value != 0;
-    else if (k == "render_pre_lds") {
-        if (value < 0 || value > 120 * 1024) return gsx::fail(c, GSX_E_INVALID, "set_option: render_pre_lds must be in [0, 122880]");
-        c->opt_render_pre_lds = (int)value;
-    }
     else if (k == "render_share_stream") {
         if ((value != 0) != (c->opt_render_share_stream != 0)) gsx::render_release_twin(c);  // the extra frames' streams are made anew
         c->opt_render_share_stream = value != 0;

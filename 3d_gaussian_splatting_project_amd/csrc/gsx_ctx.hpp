@@ -270,7 +270,6 @@ struct Ctx {
     DevBuf r_pre_args;                   // pre_multi_kernel's per-view arguments, one slot per record set
     hipEvent_t r_pre_ev[kPreSets] = {nullptr, nullptr, nullptr};  // recorded behind the pre pass that filled set s
     int r_pre_ext = -1;                  // >= 0: this frame's pre pass has been run for it into r_sets[r_pre_ext] (render_view skips its own)
-    int opt_render_pre_lds = 0;          // pre_multi_kernel: dummy dynamic LDS per workgroup (bytes) = a cap on the workgroups resident per CU
     int opt_render_multi_pre = 1;        // gsx_render_views: one pre pass per group of frames in flight (0: every frame its own)
     DevBuf r_keys0, r_keys1, r_vals0, r_vals1;
     DevBuf r_tile_order;                 // blend launch order (longest list first)

@@ -196,48 +196,64 @@ struct CoefRegs {
     __device__ __forceinline__ float get(int k, int c) const { return v[3 * k + c]; }
 };
 
-template <class Coef>
-__device__ __forceinline__ void sh_color(const Coef& cf, int deg, float px, float py, float pz, float cpx, float cpy, float cpz,
-                                         float rgb[3]) {
+// real SH basis function k of the unit direction (x, y, z): ONE set of expressions for every caller, so that the colour of a
+// splat does not depend on which kernel evaluated it (no contraction in this file; k is a compile-time constant wherever
+// this is called, the switch folds away)
+__device__ __forceinline__ float sh_basis(int k, float x, float y, float z) {
     const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
     const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                          -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    switch (k) {
+        case 0: return C0;
+        case 1: return -C1 * y;
+        case 2: return C1 * z;
+        case 3: return -C1 * x;
+        case 4: return C2[0] * xy;
+        case 5: return C2[1] * yz;
+        case 6: return C2[2] * (2.0f * zz - xx - yy);
+        case 7: return C2[3] * xz;
+        case 8: return C2[4] * (xx - yy);
+        case 9: return C3[0] * y * (3.0f * xx - yy);
+        case 10: return C3[1] * xy * z;
+        case 11: return C3[2] * y * (4.0f * zz - xx - yy);
+        case 12: return C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        case 13: return C3[4] * x * (4.0f * zz - xx - yy);
+        case 14: return C3[5] * z * (xx - yy);
+        default: return C3[6] * x * (xx - 3.0f * yy);
+    }
+}
+
+// unit vector from the camera position to the splat
+__device__ __forceinline__ void sh_dir(float px, float py, float pz, float cpx, float cpy, float cpz, float& x, float& y, float& z) {
     const float dx = px - cpx, dy = py - cpy, dz = pz - cpz;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float x = dx / len, y = dy / len, z = dz / len;
-    float b[16];
-    b[0] = C0;
-    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-    b[1] = -C1 * y;
-    b[2] = C1 * z;
-    b[3] = -C1 * x;
-    b[4] = C2[0] * xy;
-    b[5] = C2[1] * yz;
-    b[6] = C2[2] * (2.0f * zz - xx - yy);
-    b[7] = C2[3] * xz;
-    b[8] = C2[4] * (xx - yy);
-    b[9] = C3[0] * y * (3.0f * xx - yy);
-    b[10] = C3[1] * xy * z;
-    b[11] = C3[2] * y * (4.0f * zz - xx - yy);
-    b[12] = C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
-    b[13] = C3[4] * x * (4.0f * zz - xx - yy);
-    b[14] = C3[5] * z * (xx - yy);
-    b[15] = C3[6] * x * (xx - 3.0f * yy);
+    x = dx / len, y = dy / len, z = dz / len;
+}
+
+__device__ __forceinline__ float sh_clamp(float acc) {
+    const float v = acc + 0.5f;
+    return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+}
+
+template <class Coef>
+__device__ __forceinline__ void sh_color(const Coef& cf, int deg, float px, float py, float pz, float cpx, float cpy, float cpz,
+                                         float rgb[3]) {
+    float x, y, z;
+    sh_dir(px, py, pz, cpx, cpy, cpz, x, y, z);
     const int K = (deg + 1) * (deg + 1);
     float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         if (k < K) {
+            const float b = sh_basis(k, x, y, z);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b[0] * cf.get(0, c) : acc[c] + b[k] * cf.get(k, c);
+            for (int c = 0; c < 3; ++c) acc[c] = k == 0 ? b * cf.get(0, c) : acc[c] + b * cf.get(k, c);
         }
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = acc[c] + 0.5f;
-        rgb[c] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-    }
+    for (int c = 0; c < 3; ++c) rgb[c] = sh_clamp(acc[c]);
 }
 
 // ---- per view ------------------------------------------------------------------------------------------
@@ -281,27 +297,26 @@ __device__ __forceinline__ bool tile_touches(float cx, float cy, float g0x, floa
 
 static constexpr uint32_t kEmptyRect = 1u;  // tx0 = 1 > tx1 = 0: covers no tile
 
-// One splat in one view: depth key (gs.js:436-441: ((vp2 x + vp6 y + vp10 z) * 4096) | 0, fp64), vertex shader (gs.js:696-750,
-// fp32 in the oracle's operation order), colour (the reference's rgba8, or the float SH colour for the splats that are
-// actually drawn) and the tile rectangle of the ellipse's bounding box.  need_color(): called before the SH colour is
-// evaluated (pre_multi_kernel fetches the splat's coefficients there, once for all views).
-struct PreOut {
+// One splat in one view, everything but the colour: depth key (gs.js:436-441: ((vp2 x + vp6 y + vp10 z) * 4096) | 0, fp64),
+// vertex shader (gs.js:696-750, fp32 in the oracle's operation order) and the tile rectangle of the ellipse's bounding box.
+// colour: the splat reaches a pixel of this view (r0, g1 and fade are valid, a colour is wanted).
+struct PreGeom {
     int depth;
     uint32_t rect;
-    float4 r0, r1;
-    float2 r2;
+    float4 r0;       // (cx, cy, g0x, g0y)
+    float g1x, g1y;  // second axis: the first half of r1
+    float fade;
+    bool colour;
 };
 
-template <class Coef, class Need>
-__device__ __forceinline__ PreOut pre_one(const uint4 t0, const uint4 t1, const ViewUniforms& u, bool sh_on, int sh_deg, float cpx,
-                                          float cpy, float cpz, const Coef& cf, Need need_color) {
-    PreOut o;
+__device__ __forceinline__ PreGeom pre_geom(const uint4 t0, const uint4 t1, const ViewUniforms& u) {
+    PreGeom o;
     const float cx_ = __uint_as_float(t0.x), cy_ = __uint_as_float(t0.y), cz_ = __uint_as_float(t0.z);
     o.depth = js_toint32((u.vp2 * (double)cx_ + u.vp6 * (double)cy_ + u.vp10 * (double)cz_) * 4096.0);
     o.rect = kEmptyRect;
     o.r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-    o.r1 = o.r0;
-    o.r2 = make_float2(0.f, 0.f);
+    o.g1x = o.g1y = o.fade = 0.f;
+    o.colour = false;
     // ---- vertex shader, fp32 ----
     float cam[4], p2[4];
 #pragma unroll
@@ -364,24 +379,52 @@ __device__ __forceinline__ PreOut pre_one(const uint4 t0, const uint4 t1, const 
             if (x1 >= x0 && y1 >= y0) {
                 const uint32_t tx0 = x0 >> 4, tx1 = x1 >> 4, ty0 = y0 >> 4, ty1 = y1 >> 4;
                 o.rect = tx0 | (tx1 << 8) | (ty0 << 16) | (ty1 << 24);
-                // the colour is only needed for splats that reach a pixel: 192 B of SH coefficients per splat.
-                // (Deferring it further, to the splats a depth phase really bins, was measured: those are visited in
-                // DEPTH order, the coefficient reads become gathers and cost 9x what the skipped splats save.)
-                float col[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) col[k] = fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f;
-                if (sh_on) {
-                    need_color();
-                    float rgb[3];
-                    sh_color(cf, sh_deg, cx_, cy_, cz_, cpx, cpy, cpz, rgb);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) col[k] = fade * rgb[k];
-                }
                 o.r0 = make_float4(wcx, wcy, 2.0f * mx / m2, 2.0f * my / m2);
-                o.r1 = make_float4(2.0f * nx / n2, 2.0f * ny / n2, col[0], col[1]);
-                o.r2 = make_float2(col[2], col[3]);
+                o.g1x = 2.0f * nx / n2;
+                o.g1y = 2.0f * ny / n2;
+                o.fade = fade;
+                o.colour = true;
             }
         }
+    }
+    return o;
+}
+
+// the reference's colour: fade * rgba8 / 255 (gs.js:741-742); the SH colour replaces its first three channels
+__device__ __forceinline__ float rgba8_channel(const uint4 t1, int k, float fade) { return fade * (float)((t1.w >> (8 * k)) & 0xffu) / 255.0f; }
+
+// One splat in one view, complete (pre_kernel).  The colour is only needed for splats that reach a pixel: 192 B of SH
+// coefficients per splat.  (Deferring it further, to the splats a depth phase really bins, was measured: those are visited in
+// DEPTH order, the coefficient reads become gathers and cost 9x what the skipped splats save.)
+struct PreOut {
+    int depth;
+    uint32_t rect;
+    float4 r0, r1;
+    float2 r2;
+};
+
+template <class Coef>
+__device__ __forceinline__ PreOut pre_one(const uint4 t0, const uint4 t1, const ViewUniforms& u, bool sh_on, int sh_deg, float cpx,
+                                          float cpy, float cpz, const Coef& cf) {
+    const PreGeom g = pre_geom(t0, t1, u);
+    PreOut o;
+    o.depth = g.depth;
+    o.rect = g.rect;
+    o.r0 = g.r0;
+    o.r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    o.r2 = make_float2(0.f, 0.f);
+    if (g.colour) {
+        float col[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[k] = rgba8_channel(t1, k, g.fade);
+        if (sh_on) {
+            float rgb[3];
+            sh_color(cf, sh_deg, __uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), cpx, cpy, cpz, rgb);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) col[k] = g.fade * rgb[k];
+        }
+        o.r1 = make_float4(g.g1x, g.g1y, col[0], col[1]);
+        o.r2 = make_float2(col[2], col[3]);
     }
     return o;
 }
@@ -420,7 +463,7 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
     for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
         const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
         const CoefMem cf{sh_coef, n, i};
-        const PreOut o = pre_one(t0, t1, u, sh_coef != nullptr, sh_deg, cpx, cpy, cpz, cf, [] {});
+        const PreOut o = pre_one(t0, t1, u, sh_coef != nullptr, sh_deg, cpx, cpy, cpz, cf);
         depth[i] = o.depth;
         lo = min(lo, o.depth);
         hi = max(hi, o.depth);
@@ -433,10 +476,15 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
     depth_range_to(lo, hi, pre, slo, shi);
 }
 
-// The same for up to kPreViews views in ONE pass over the scene: a splat's texel pair is read once and its SH coefficients
-// (192 B at degree 3) come from HBM once - gsx_render_views keeps several frames in flight, and each of them used to stream
-// the whole scene again (4 x 816 MB at 3 M splats).  Per view the operations are pre_kernel's, on the same operands: the
-// frames are bit-identical.
+// The same for NV views (1 .. kPreViews) in ONE pass over the scene: a splat's texel pair and its SH coefficients (224 B at
+// degree 3) are read ONCE - gsx_render_views keeps several frames in flight, and each of them used to stream the whole scene
+// again (4 x 816 MB at 3 M splats).  The loop is turned inside out for that: first the geometry of every view (pre_geom, the
+// code pre_kernel runs), then one pass over the coefficients in which every view that draws the splat accumulates its own
+// colour - three accumulators and a direction per view, the basis function recomputed from the direction when its
+// coefficient arrives (sh_basis: the expressions of sh_color).  Per view the operations are pre_kernel's in pre_kernel's
+// order, on the same operands: the frames are bit-identical.  (Two earlier forms, both measured: the view loop around
+// pre_one with the coefficients re-read through L2 - they had left the 4 MB L2 by the next view, 2.2 GB fetched per 4-view
+// launch instead of 0.67 - and with the coefficients held in 48 registers across the views - spills.)
 static constexpr int kPreViews = Ctx::kMaxFrames;
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void nt_store4(float4* p, const float4 v) {
@@ -455,43 +503,85 @@ struct PreMultiArgs {
     int nv;
 };
 
+template <int NV>
 __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict__ tex, long long n, const float* __restrict__ sh_coef,
                                                          int sh_deg, const PreMultiArgs* __restrict__ ap) {
-    // (the arguments live in device memory: indexed by the view they are scalar loads; passed by value the struct was
-    // promoted to 350 vector registers)
+    // (the arguments live in device memory: the views' uniforms are scalar loads)
     const PreMultiArgs& a = *ap;
     __shared__ int slo[4], shi[4];
-    // per-thread depth range of every view: thread-private columns of LDS (the view loop below is a REAL loop - unrolled six
-    // times the kernel needed 256 VGPRs and ran one wave per SIMD - so the ranges cannot sit in registers)
-    __shared__ int vlo[kPreViews][kRB], vhi[kPreViews][kRB];
-    const int nv = a.nv;
-    for (int v = 0; v < nv; ++v) vlo[v][threadIdx.x] = 2147483647, vhi[v][threadIdx.x] = -2147483647 - 1;
+    int lo[NV], hi[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) lo[v] = 2147483647, hi[v] = -2147483647 - 1;
+    const int K = (sh_deg + 1) * (sh_deg + 1);
     for (long long i = (long long)blockIdx.x * kRB + threadIdx.x; i < n; i += (long long)gridDim.x * kRB) {
         const uint4 t0 = tex[2 * i], t1 = tex[2 * i + 1];
-        // The SH coefficients are read through memory by every view that draws the splat (CoefMem, as in pre_kernel): the first
-        // view brings them in from HBM, the others find them in L2 a few hundred cycles later.  (Holding the 48 of them in
-        // registers across the views cost 48 VGPRs on top of the vertex shader's 60 and spilled.)
-#pragma unroll 1
-        for (int v = 0; v < nv; ++v) {  // wave-uniform: the view's uniforms come through scalar loads
-            long long ii = i;
-            asm volatile("" : "+v"(ii));  // (keeps the 48 coefficient addresses out of the loop's invariants: 96 VGPRs)
-            const CoefMem cf{sh_coef, n, ii};
-            const PreOut o = pre_one(t0, t1, a.u[v], sh_coef != nullptr, sh_deg, a.cam[v][0], a.cam[v][1], a.cam[v][2], cf, [] {});
-            // streaming stores: the records are not read again by this kernel, and written the ordinary way they push the
-            // splat's coefficients out of the 4 MB L2 before the next view of this loop asks for them again
-            __builtin_nontemporal_store(o.depth, &a.depth[v][i]);
-            vlo[v][threadIdx.x] = min(vlo[v][threadIdx.x], o.depth);
-            vhi[v][threadIdx.x] = max(vhi[v][threadIdx.x], o.depth);
-            nt_store4(&a.rec0[v][i], o.r0);
-            nt_store4(&a.rec1[v][i], o.r1);
-            __builtin_nontemporal_store(o.r2.x, &a.rec2[v][i].x);
-            __builtin_nontemporal_store(o.r2.y, &a.rec2[v][i].y);
-            __builtin_nontemporal_store(o.rect, &a.rect[v][i]);
-            if (i == 0) a.pre[v][2] = (int)o.rect;
+        const float px = __uint_as_float(t0.x), py = __uint_as_float(t0.y), pz = __uint_as_float(t0.z);
+        // ---- geometry of every view: depth key, rectangle and the first record go out at once; what the colour needs stays
+        float g1x[NV], g1y[NV], fade[NV];
+        unsigned want = 0;  // bit v: view v wants a colour for this splat
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            // (the pointer is laundered so that a view's 44 uniforms are scalar loads HERE, dead after its vertex shader: hoisted out
+            // of the splat loop as invariants, the uniforms of four views are 375 spilled SGPRs)
+            const PreMultiArgs* av = ap;
+            asm volatile("" : "+s"(av));
+            const PreGeom g = pre_geom(t0, t1, av->u[v]);
+            __builtin_nontemporal_store(g.depth, &a.depth[v][i]);  // streaming stores: the records are not read again here
+            lo[v] = min(lo[v], g.depth);
+            hi[v] = max(hi[v], g.depth);
+            nt_store4(&a.rec0[v][i], g.r0);
+            __builtin_nontemporal_store(g.rect, &a.rect[v][i]);
+            if (i == 0) a.pre[v][2] = (int)g.rect;
+            g1x[v] = g.g1x, g1y[v] = g.g1y, fade[v] = g.fade;
+            want |= g.colour ? 1u << v : 0u;
+            __builtin_amdgcn_sched_barrier(0);  // one view after the other: interleaved, the six vertex shaders need 256 VGPRs
+        }
+        // ---- colour: the coefficients are read ONCE (if any view draws the splat) and every view accumulates its own sum, in
+        // sh_color's order: acc = b_0 p_0, then acc += b_k p_k for k = 1 .. K-1, the basis recomputed from the view's direction
+        float acc[NV][3], dx[NV], dy[NV], dz[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            acc[v][0] = acc[v][1] = acc[v][2] = 0.f;
+            sh_dir(px, py, pz, a.cam[v][0], a.cam[v][1], a.cam[v][2], dx[v], dy[v], dz[v]);
+        }
+        if (sh_coef != nullptr && want != 0u) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < K) {
+                    float p[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p[c] = sh_coef[((size_t)k * 3 + c) * (size_t)n + (size_t)i];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const float b = sh_basis(k, dx[v], dy[v], dz[v]);
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) acc[v][c] = k == 0 ? b * p[c] : acc[v][c] + b * p[c];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float2 r2 = make_float2(0.f, 0.f);
+            if ((want >> v) & 1u) {
+                float col[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) col[k] = rgba8_channel(t1, k, fade[v]);
+                if (sh_coef != nullptr) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) col[c] = fade[v] * sh_clamp(acc[v][c]);
+                }
+                r1 = make_float4(g1x[v], g1y[v], col[0], col[1]);
+                r2 = make_float2(col[2], col[3]);
+            }
+            nt_store4(&a.rec1[v][i], r1);
+            __builtin_nontemporal_store(r2.x, &a.rec2[v][i].x);
+            __builtin_nontemporal_store(r2.y, &a.rec2[v][i].y);
         }
     }
-#pragma unroll 1
-    for (int v = 0; v < nv; ++v) depth_range_to(vlo[v][threadIdx.x], vhi[v][threadIdx.x], a.pre[v], slo, shi);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) depth_range_to(lo[v], hi[v], a.pre[v], slo, shi);
 }
 
 // 16-bit depth bucket (gs.js:443-447) once the depth range is known; doubles as the (key, value) initialisation of the
@@ -1198,12 +1288,11 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         }
         PreMultiArgs* a_dev = c->r_pre_args.as<PreMultiArgs>() + set;
         GSX_HIP(c, hipMemcpyAsync(a_dev, &a, sizeof a, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
-        // opt_render_pre_lds: bytes of LDS the launch asks for and never touches - it caps the workgroups resident per CU, i.e. the
-        // bytes of coefficients in flight between a splat's first view and its next ones, which must fit the 4 MB L2 of an XCD
-        if (c->opt_render_pre_lds > 0)
-            GSX_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(pre_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           c->opt_render_pre_lds));
-        hipLaunchKernelGGL(pre_multi_kernel, dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), (size_t)std::max(0, c->opt_render_pre_lds), c->stream, c->r_tex.as<uint4>(),
+        using PK = void (*)(const uint4*, long long, const float*, int, const PreMultiArgs*);
+        static const PK kernels[kPreViews] = {pre_multi_kernel<1>, pre_multi_kernel<2>, pre_multi_kernel<3>,
+                                              pre_multi_kernel<4>, pre_multi_kernel<5>, pre_multi_kernel<6>};
+        static_assert(kPreViews == 6, "one instantiation per group size");
+        hipLaunchKernelGGL(kernels[a.nv - 1], dim3(std::min<unsigned>(grid_for(c->rn), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(),
                            (long long)c->rn, c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, a_dev);
         GSX_HIP(c, hipGetLastError());
         GSX_HIP(c, hipEventRecord(c->r_pre_ev[set], c->stream));
