@@ -268,6 +268,7 @@ struct Ctx {
     static constexpr int kPreSets = 3;
     PreSet r_sets[kPreSets];
     DevBuf r_pre_args;                   // pre_multi_kernel's per-view arguments, one slot per record set
+    std::vector<unsigned long long> r_pre_args_host;  // ... and their host copies (8-byte aligned; alive while the H2D copies run)
     hipEvent_t r_pre_ev[kPreSets] = {nullptr, nullptr, nullptr};  // recorded behind the pre pass that filled set s
     int r_pre_ext = -1;                  // >= 0: this frame's pre pass has been run for it into r_sets[r_pre_ext] (render_view skips its own)
     int opt_render_multi_pre = 1;        // gsx_render_views: one pre pass per group of frames in flight (0: every frame its own)

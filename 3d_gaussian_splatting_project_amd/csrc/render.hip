@@ -1262,6 +1262,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             for (Ctx::PreSet& ps : ctxs[f]->r_sets)
                 if ((rc = ensure_pre_set(c, ps, c->rn))) return rc;
         GSX_HIP(c, c->r_pre_args.ensure(sizeof(PreMultiArgs) * Ctx::kPreSets));
+        c->r_pre_args_host.resize((sizeof(PreMultiArgs) * Ctx::kPreSets + 7) / 8);
         for (int s = 0; s < Ctx::kPreSets; ++s)
             if (!c->r_pre_ev[s]) GSX_HIP(c, hipEventCreateWithFlags(&c->r_pre_ev[s], hipEventDisableTiming));
     }
@@ -1270,8 +1271,11 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         for (int f = 0; f < F; ++f)
             while (done[f].load(std::memory_order_acquire) < std::min(g - 2, (n - 1 - f) / F + 1) && !failed.load()) std::this_thread::yield();
         if (failed.load()) return GSX_OK;
-        PreMultiArgs a{};
         const int set = g % Ctx::kPreSets;
+        // the host copy of the arguments lives in the context, one slot per record set: the asynchronous copy below may read it
+        // after this function has returned (a slot is rewritten three groups later)
+        PreMultiArgs& a = reinterpret_cast<PreMultiArgs*>(c->r_pre_args_host.data())[set];
+        a = PreMultiArgs{};
         a.nv = std::min(F, n - g * F);
         for (int v = 0; v < a.nv; ++v) {
             const gsx_camera* cam = cams + (g * F + v);
@@ -1287,7 +1291,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             GSX_HIP(c, hipMemcpyAsync(ps.pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
         }
         PreMultiArgs* a_dev = c->r_pre_args.as<PreMultiArgs>() + set;
-        GSX_HIP(c, hipMemcpyAsync(a_dev, &a, sizeof a, hipMemcpyHostToDevice, c->stream));  // (pageable source: staged before the call returns)
+        GSX_HIP(c, hipMemcpyAsync(a_dev, &a, sizeof a, hipMemcpyHostToDevice, c->stream));
         using PK = void (*)(const uint4*, long long, const float*, int, const PreMultiArgs*);
         static const PK kernels[kPreViews] = {pre_multi_kernel<1>, pre_multi_kernel<2>, pre_multi_kernel<3>,
                                               pre_multi_kernel<4>, pre_multi_kernel<5>, pre_multi_kernel<6>};
@@ -1305,6 +1309,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             if (multi) {
                 if (f == 0) {  // this thread: the pass of the NEXT group goes out before this group's frame (group 0's before the threads start)
                     if (g + 1 < groups && (rcs[f] = issue_pre(g + 1))) break;
+                    if (failed.load()) break;  // (a pass that was not issued leaves no records to render from)
                 } else {
                     while (pre_issued.load(std::memory_order_acquire) < g + 1 && !failed.load()) std::this_thread::yield();
                     if (failed.load()) break;
