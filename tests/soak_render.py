@@ -2,7 +2,7 @@
 """Randomised soak of the rasterizer against the oracle (GPU box): scene sizes from a handful of splats to tens of
 thousands, frames that are not multiples of 16, splats from sub-pixel to frame-filling, cameras inside and outside the
 cloud, 1-8 depth phases and phase ratios, exact tile culling on and off, all three blend kernels, SH degree 0-3, single
-frames and gsx_render_views.  Every frame within 1e-4 of the oracle's.  Usage: tests/soak_render.py SEED TRIALS"""
+frames and gsx_render_views with 1-6 frames in flight and one pre pass per group of frames or per frame.  Every frame within 1e-4 of the oracle's.  Usage: tests/soak_render.py SEED TRIALS"""
 import importlib
 import os
 import sys
@@ -27,7 +27,8 @@ with gsx.Context(0) as c:
         W, H = int(rng.integers(17, 500)), int(rng.integers(17, 400))
         deg = int(rng.choice([0, 0, 1, 2, 3]))
         opts = {"render_phases": int(rng.integers(1, 9)), "render_phase_ratio": int(rng.choice([2, 3, 4, 8])),
-                "exact_cull": int(rng.random() < 0.5), "blend_pk2": int(rng.integers(0, 3)), "tile_lpt": int(rng.random() < 0.2)}
+                "exact_cull": int(rng.random() < 0.5), "blend_pk2": int(rng.integers(0, 3)), "tile_lpt": int(rng.random() < 0.2),
+                "render_frames": int(rng.integers(1, 7)), "render_multi_pre": int(rng.random() < 0.8)}
         for k, v in opts.items():
             c.set_option(k, v)
         s = scene.BASE_SEED + int(rng.integers(1 << 20))
@@ -45,7 +46,7 @@ with gsx.Context(0) as c:
         k1 = (deg + 1) ** 2 - 1
         if deg:
             c.upload_sh(a["f_rest"][:, :3 * k1], deg)
-        use = cams[:int(rng.integers(1, 4))]
+        use = cams[:int(rng.integers(1, 6))]
         frames = c.render_views(use, W, H) if rng.random() < 0.5 else np.stack([c.render_view(cam, W, H) for cam in use])
         for cam, got in zip(use, frames):
             if deg:

@@ -771,6 +771,7 @@ def test_import_uniform_and_undo(gsx):
         ptr, used, blobs = c.vote_export(0)
         stride = used // V
         pool = gsx.dist.device_bytes_tensor(ptr, used, 0).clone()
+        torch.cuda.synchronize()                                               # torch's stream wrote it, the context's stream reads it
         with pytest.raises(gsx.GsxError):
             c.vote_import_undo()                                               # nothing imported yet
         for parts, offs in (([V], [0]), ([3, 4], [0, 3 * stride]), ([1, 0, 6], [0, stride, stride])):
@@ -781,6 +782,7 @@ def test_import_uniform_and_undo(gsx):
                 kp, _ = c.keys_device()
                 c.synchronize()
                 slabs.append(gsx.dist.device_words_tensor(kp, sn, 0).clone())
+                torch.cuda.synchronize()                                       # before the next slab's vote reuses the key buffer
             full = torch.cat(slabs)
             torch.cuda.synchronize()
             assert np.array_equal(c.vote_labels_from_sorted(full.data_ptr()), want), parts
