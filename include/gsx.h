@@ -126,7 +126,15 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               phases, 2.2 M consumed).  What is skipped could not have moved a channel by 1e-5
  *   "render_phase_ratio" (default 4)  phase p ends after n / ratio^(K-1-p) splats of the depth order (2..64)
  *   "render_frames" (default 4) gsx_render_views: frames in flight, each on a HIP stream of its own (1..6; 935 / 1252 /
- *                               1359 / 1396 / 1296 / 1349 views/s with 1..6 at 3 M splats @1080p SH 3)
+ *                               1359 / 1396 / 1296 / 1349 views/s with 1..6 at 3 M splats @1080p SH 3: four streams for the
+ *                               four hardware queues)
+ *   "render_multi_pre" (default 1)  gsx_render_views: ONE pre pass (depth keys, vertex shader, colours, tile rectangles) per
+ *                               group of frames in flight instead of one per frame: a splat's texel pair and SH coefficients
+ *                               are read once for all views of the group (168 MB per view instead of 816 at 3 M splats, SH
+ *                               3).  Bit-identical frames
+ *   "render_share_stream" (default 1)  gsx_render_views: the first extra frame runs on the context's second stream (the
+ *                               early vote's) instead of one more stream - a context that has labelled before would
+ *                               otherwise hold five streams for four hardware queues (1120 instead of 1340 views/s)
  *   "exact_cull"   (default 0)  rasterizer: bin a splat only into the tiles its |vPosition| <= 2 ellipse reaches
  *                               (minimum of the quadratic over the tile), not its whole bounding box.  The binning
  *                               is wave-cooperative (no lane walks a rectangle on its own), yet on the 3 M-splat
