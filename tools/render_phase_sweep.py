@@ -15,16 +15,19 @@ cams = scene.make_cameras(24, W, H, convention="c2w")
 with pkg.Context(0) as c:
     c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
     c.upload_sh(a["f_rest"], 3)
-    for opts in ({}, {"render_phases": 3}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 2, "render_phase_ratio": 8},
-                 {"render_phases": 2, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 3}, {"exact_cull": 1},
-                 {"render_phases": 3, "exact_cull": 1}, {"tile_lpt": 0}, {}):
-        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 1}
+    sweep = ({}, {"render_phases": 3}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 2, "render_phase_ratio": 8},
+             {"render_phases": 2, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 3}, {"exact_cull": 1},
+             {"render_phases": 3, "exact_cull": 1}, {"tile_lpt": 1}, {})
+    if len(sys.argv) > 1 and sys.argv[1] == "ab":      # a clean A/B of the two candidates, interleaved three times
+        sweep = ({}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3}) * 3 + ({},)
+    for opts in sweep:
+        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0}
         base.update(opts)
         for k, v in base.items():
             c.set_option(k, v)
         c.render_views(cams, W, H, to_host=False)
         t0 = time.perf_counter()
-        for rep in range(3):
+        for rep in range(5):
             c.render_views(cams, W, H, to_host=False)
-        dt = (time.perf_counter() - t0) / (3 * len(cams))
+        dt = (time.perf_counter() - t0) / (5 * len(cams))
         print(f"{opts}: {dt * 1e3:.3f} ms/view = {1 / dt:.0f} views/s   pairs sorted {c.render_num_pairs() // len(cams)}  consumed {c.render_num_pairs_consumed() // len(cams)}", flush=True)
