@@ -253,6 +253,9 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    import gc
+    gc.collect()   # (a full collection of the set-up's garbage now, not in the middle of a timed step: r03's records show single 11-17 ms
+                   # steps among 8 ms ones without any cgroup throttling; the collector itself stays on)
     ctx.vote_culled(reset=True)
     if not args.no_profile:
         ctx.profile(True)
