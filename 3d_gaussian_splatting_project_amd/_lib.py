@@ -98,6 +98,7 @@ _SIGS = {
                                           C.c_void_p, C.c_int64]),
     "gsx_vote_slab_labels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
     "gsx_host_threads": (C.c_int, [C.c_void_p]),
+    "gsx_default_host_threads": (C.c_int, []),
     "gsx_profile_name": (C.c_char_p, [C.c_void_p, C.c_int32]),
     "gsx_vote_debug_planes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "gsx_upload_splats": (C.c_int, [C.c_void_p, C.c_int64] + [C.c_void_p] * 6),

@@ -506,6 +506,7 @@ int gsx_host_threads(gsx_ctx* ctx) {
         return 1;  // no pool: maps are packed on the calling thread
     }
 }
+int gsx_default_host_threads(void) { return gsx::default_host_threads(); }
 int gsx_vote_debug_planes(gsx_ctx* ctx, uint16_t* counts_out, uint16_t* first_out) {
     CTX_OR_FAIL(ctx);
     return gsx::guard(c, __func__, [&] { return gsx::vote_debug_planes(c, counts_out, first_out); });

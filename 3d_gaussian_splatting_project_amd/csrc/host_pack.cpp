@@ -273,6 +273,32 @@ void Workers::run(int parts, void (*fn)(void*, int), void* arg) {
     while (s.remaining.load(std::memory_order_acquire) != 0) cpu_relax();
 }
 
+// CPUs' worth of time the cgroup of this process may use per scheduler period (cgroup v2 cpu.max, v1 cfs quota), 0 = unlimited
+// or unknown.
+static double cgroup_cpu_quota() {
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        double period = 0.0;
+        const int got = std::fscanf(f, "%31s %lf", q, &period);
+        std::fclose(f);
+        if (got == 2 && period > 0.0 && std::strcmp(q, "max") != 0) {
+            const double v = std::atof(q);
+            return v > 0.0 ? v / period : 0.0;
+        }
+        return 0.0;
+    }
+    double quota = 0.0, period = 0.0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(f, "%lf", &quota) != 1) quota = 0.0;
+        std::fclose(f);
+    }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(f, "%lf", &period) != 1) period = 0.0;
+        std::fclose(f);
+    }
+    return quota > 0.0 && period > 0.0 ? quota / period : 0.0;
+}
+
 int default_host_threads() {
     if (const char* e = std::getenv("GSX_HOST_THREADS")) {
         const int v = std::atoi(e);
@@ -283,6 +309,16 @@ int default_host_threads() {
     if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
     if (cpus < 1) cpus = (int)std::thread::hardware_concurrency();
     if (cpus < 1) cpus = 1;
+    // A CPU-time quota of the process's cgroup counts like fewer CPUs: the workers spin between the maps of a run, and threads
+    // beyond the quota only get the whole group frozen for the rest of a scheduler period.
+    const double quota = cgroup_cpu_quota();
+    if (quota > 0.0 && quota < (double)cpus) cpus = quota < 1.0 ? 1 : (int)quota;
+    // One process per GPU: the ranks of a node share its CPUs (and the quota).  torch.distributed.run exports the number of
+    // ranks on this node.
+    if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+        const int ranks = std::atoi(e);
+        if (ranks > 1) cpus = cpus / ranks < 1 ? 1 : cpus / ranks;
+    }
     return cpus > 16 ? 16 : cpus;
 }
 

@@ -42,7 +42,7 @@ private:
     int nthreads_;
 };
 int numa_node_of(const void* addr);  // NUMA node holding that page, -1 if unknown
-int default_host_threads();  // min(16, CPUs this process may run on), or GSX_HOST_THREADS
+int default_host_threads();  // min(16, (CPUs this process may run on, capped by the cgroup quota) / LOCAL_WORLD_SIZE), or GSX_HOST_THREADS
 
 // seg dtype codes as in gsx.h: 0 = int32, 1 = int64, 2 = u8 holding label+1, 3 = u8 holding the label.
 // Writes the packed map (layout L) at dst; returns 0, or 1 if a label lies outside [-1, bins-2].

@@ -250,15 +250,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Everything that changes the process's state happens BEFORE the warm-up, so the warm-up steps run exactly as the timed ones do
+    # (r03's records show the FIRST timed step at 11-17 ms among 8 ms ones without any cgroup throttling when the per-kernel events
+    # were switched on and the set-up's garbage collected between the warm-up and the timed region).  The collector itself stays on.
+    import gc
+    gc.collect()
+    if not args.no_profile:
+        ctx.profile(True)
     for _ in range(args.warmup):
         step()
     fence()
-    import gc
-    gc.collect()   # (a full collection of the set-up's garbage now, not in the middle of a timed step: r03's records show single 11-17 ms
-                   # steps among 8 ms ones without any cgroup throttling; the collector itself stays on)
     ctx.vote_culled(reset=True)
     if not args.no_profile:
-        ctx.profile(True)
+        ctx.profile(True)   # drops the warm-up's figures (the events are recycled, nothing is created or freed)
     thr0 = _cpu_throttle()
     step_ms = []
     t0 = time.perf_counter()

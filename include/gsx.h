@@ -196,7 +196,9 @@ int gsx_vote_begin(gsx_ctx* ctx, int32_t n_classes, int32_t first_view, int32_t 
  * 16-byte block per cell whose pixels differ (option "host_compact"); one asynchronous DMA per group of up to 16 maps moves
  * the records and a kernel queued behind it rebuilds the two-level on-device map.  Nothing is synchronised: 200 calls
  * cost the host pass over the maps (the link carries ~0.3 MB per 1080p map of an ordinary segmentation, 2.2 MB at worst).
- * Option "host_threads" (default 0 = min(16, usable CPUs), env GSX_HOST_THREADS) sizes the worker pool.
+ * Option "host_threads" sizes the worker pool; default 0 = gsx_default_host_threads(): min(16, usable CPUs), where the usable
+ * CPUs are the affinity mask capped by the cgroup's CPU quota and divided by LOCAL_WORLD_SIZE (the ranks torch.distributed.run
+ * started on this node: one process per GPU share the node's CPUs); env GSX_HOST_THREADS overrides it.
  * Option "host_pack" = 0 selects the alternative hand-over: the workers only copy the raw map into pinned memory, the raw
  * bytes cross PCIe (4x as many for int32) and the fused kernel of gsx_vote_view_device packs them; the range check is
  * then the deferred device-side one.  Measured slower on the GPU box; for hosts short of cores. */
@@ -466,6 +468,8 @@ int gsx_profile_reset(gsx_ctx* ctx);
 const char* gsx_profile_name(gsx_ctx* ctx, int32_t index);
 /* worker threads (including the caller) gsx_vote_view packs host maps with; starts the pool if need be */
 int gsx_host_threads(gsx_ctx* ctx);
+/* the pool size a context would choose on its own in this process right now (no context, no GPU needed) */
+int gsx_default_host_threads(void);
 /* name: "vote_fused_labels", "seg_pack", ...; returns launches and total milliseconds since reset */
 int gsx_profile_get(gsx_ctx* ctx, const char* name, int64_t* launches, double* total_ms);
 

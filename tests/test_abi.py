@@ -48,3 +48,28 @@ def test_no_cpu_fallback_and_null_handling():
         with pytest.raises(g.GsxError) as e:
             g.Context(0)
         assert e.value.code == g._lib.GSX_E_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_default_host_threads_shares_the_node_between_ranks():
+    """gsx_default_host_threads: min(16, usable CPUs / ranks on this node); env GSX_HOST_THREADS wins.  One process per GPU."""
+    import subprocess
+    import sys
+    g = load_pkg()
+    g.build()
+    code = ("import ctypes,sys; l=ctypes.CDLL(sys.argv[1]); l.gsx_default_host_threads.restype=ctypes.c_int; "
+            "print(l.gsx_default_host_threads())")
+
+    def ask(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("GSX_HOST_THREADS", "LOCAL_WORLD_SIZE")}
+        e.update(env)
+        return int(subprocess.run([sys.executable, "-c", code, g._lib.SO_PATH], env=e, check=True, capture_output=True,
+                                  text=True).stdout)
+
+    cpus = len(os.sched_getaffinity(0))
+    alone = ask()
+    assert 1 <= alone <= min(16, cpus)   # a cgroup quota may lower it further
+    assert ask(LOCAL_WORLD_SIZE="1") == alone
+    shared = ask(LOCAL_WORLD_SIZE="8")
+    assert 1 <= shared <= max(1, cpus // 8) and shared <= alone
+    assert ask(LOCAL_WORLD_SIZE="100000") == 1
+    assert ask(GSX_HOST_THREADS="3", LOCAL_WORLD_SIZE="8") == 3
