@@ -15,8 +15,13 @@
  *
  * Parity status.  The JavaScript half (pack / texture / matrices / depth order) is PINNED byte for
  * byte by tests/golden/render_js.npz, produced by running the reference's own worker under node
- * (tools/make_golden_js.js).  The GLSL half cannot be executed here (no GL stack): its restatement is
- * checked by known-answer tests only -> "parity unpinned" for gsxo_vertex / gsxo_render_view.
+ * (tools/make_golden_js.js).  The GLSL half (gsxo_vertex / gsxo_render_view) is PINNED since round 3 by
+ * tests/golden/render_gl_{cases,scenes}.npz: frames of the reference's own vertex + fragment shaders and blend state
+ * executed by Mesa llvmpipe (the software OpenGL ES 3.2 of the image, reached through the DRI swrast interface:
+ * tools/gl_reference/gl_frames.c, tests/golden/make_golden_gl.py) on the reference's own texture / depthIndex -
+ * <= 1e-4 per channel on every pixel except fragments that sit on the discard threshold A = -4, which GL's
+ * 1/256-pixel vertex snapping decides (1 pixel in ~80 000 over 124 random frames, profiles/r03/gl_reference_soak.txt).
+ * Rounds 1-2 had known-answer tests only.  The SH colour (gsxo_sh_colors) stays "parity unpinned": gs.js reads f_dc only.
  * JavaScript numbers are fp64 and never fused: build with -ffp-contract=off.  GLSL highp float is
  * restated in fp32 without contraction.
  */

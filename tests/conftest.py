@@ -64,3 +64,35 @@ def golden_assign_cases():
             sizes.append((int(P("img_wh")[v][0]), int(P("img_wh")[v][1])))
         out.append((str(case), P("positions"), cams, segs, sizes, P("labels")))
     return out
+
+
+# ---- frames of the reference's own GLSL on Mesa llvmpipe (tests/golden/make_golden_gl.py) ---------------------------------------
+GL_TOL = 1e-4                      # BASELINE.json north_star: "within 1e-4" of the WebGL fragment output
+GL_FLIP = float(np.exp(-4.0))      # a fragment EXACTLY on the discard threshold A = -4 adds at most alpha * e^-4 per channel
+
+
+def gl_golden_calls():
+    """[(id, xyz, scale, rot, opacity, f_dc, cam dict, W, H, frame)] of both GL fixtures."""
+    out = []
+    for name in ("render_gl_cases.npz", "render_gl_scenes.npz"):
+        z = np.load(os.path.join(GOLDEN, name))
+        for i in (int(k) for k in z["calls"]):
+            j = int(z[f"c{i}_scene"])
+            fx, fy, W, H = z[f"c{i}_cam"]
+            cam = cam_dict(fx, fy, (int(W), int(H)), z[f"c{i}_R"], z[f"c{i}_p"])
+            out.append((f"{name.split('.')[0]}-{i}", z[f"s{j}_xyz"], z[f"s{j}_scale"], z[f"s{j}_rot"], z[f"s{j}_opacity"], z[f"s{j}_f_dc"],
+                        cam, int(W), int(H), z[f"c{i}_frame"]))
+    return out
+
+
+def check_against_gl_frame(img, frame, what):
+    """<= 1e-4 on every channel of every pixel - except that a fragment which lies exactly ON the shader's discard threshold
+    (A = -|vPosition|^2 = -4 to the last bit, e.g. a 3-pixel sigma centred on a pixel centre, offsets (6, 6)) may be kept by one
+    implementation and discarded by the other (GL interpolates vPosition across the quad, with its own rounding): at most two
+    such pixels per frame, each off by no more than one fragment at the threshold, alpha * e^-4 <= 0.0184."""
+    assert img.shape == frame.shape and np.isfinite(frame).all() and np.isfinite(img).all(), what
+    d = np.abs(img.astype(np.float64) - frame).max(axis=2)
+    over = int((d > GL_TOL).sum())
+    assert over <= 2, f"{what}: {over} pixels differ from the reference's shaders by more than {GL_TOL} (max {d.max():.3e})"
+    assert d.max() <= GL_FLIP + GL_TOL, f"{what}: max abs difference {d.max():.3e}"
+    return float(d.max()), over

@@ -1,6 +1,7 @@
 """CPU: the viewer-path oracle (oracle/render_oracle.c) against the golden vectors produced by running
 the reference's own worker code under node (tools/make_golden_js.js), plus known-answer tests of the
-shader restatement (the GLSL itself cannot run here: parity unpinned, see the oracle header)."""
+shader restatement, and - round 3 - against frames of the reference's OWN GLSL executed by Mesa llvmpipe
+(tests/golden/make_golden_gl.py, tools/gl_reference/gl_frames.c): the vertex/fragment half is pinned too."""
 import os
 
 import numpy as np
@@ -8,7 +9,7 @@ import pytest
 
 import oracle
 import render_cases
-from conftest import GOLDEN, cam_dict
+from conftest import GOLDEN, cam_dict, check_against_gl_frame, gl_golden_calls
 
 
 @pytest.fixture(scope="module")
@@ -93,3 +94,21 @@ def test_hit_test_matches_node(g):
             assert oracle.hit_test(g["buffer"], lab, cam, W, H, x, y)[0] == w
             hits += w != -999999
     assert hits > 300
+
+
+def test_oracle_matches_the_reference_shaders_run_on_llvmpipe():
+    """oracle/render_oracle.c (pack -> texture -> order -> vertex -> fragment -> blend) against the frames the reference's own
+    shaders and blend state produce on Mesa llvmpipe from the reference's own texture and depthIndex (gs.js:661-800, 1033-1038,
+    1608-1609): every known-answer case and the dense scenes, <= 1e-4 (flips at the discard threshold: see conftest)."""
+    calls = gl_golden_calls()
+    assert len(calls) >= 18
+    worst, flips, covered = 0.0, 0, 0
+    for cid, xyz, scale, rot, opacity, f_dc, cam, W, H, frame in calls:
+        img = oracle.render_scene(xyz, scale, rot, opacity, f_dc, cam, W, H)
+        d, over = check_against_gl_frame(img, frame, cid)
+        if over == 0:
+            worst = max(worst, d)
+            assert np.array_equal(img[..., 3] > 0, frame[..., 3] > 0), f"{cid}: coverage differs"
+        flips += over
+        covered += int((frame[..., 3] > 0).sum())
+    assert worst <= 1e-4 and flips <= 2 and covered > 80_000     # (two threshold pixels in the depth-fade case, none elsewhere)

@@ -9,7 +9,7 @@ import pytest
 
 import oracle
 import render_cases
-from conftest import GOLDEN, cam_dict
+from conftest import GOLDEN, cam_dict, check_against_gl_frame, gl_golden_calls
 
 pytestmark = pytest.mark.gpu
 scene = importlib.import_module("3d_gaussian_splatting_project_amd.scene")
@@ -65,6 +65,29 @@ def hip_render_factory(ctx):
                           np.asarray(opacity, np.float32), np.asarray(f_dc, np.float32))
         return ctx.render_view(cam, W, H)
     return render
+
+
+def test_frames_match_the_reference_shaders_run_on_llvmpipe(ctx):
+    """The HIP rasterizer, from raw 3DGS attributes, against the frames of the reference's OWN vertex + fragment shaders and blend
+    state (gs.js:661-800, 1033-1038, 1608-1609) executed by Mesa llvmpipe on the reference's own texture / depthIndex
+    (tests/golden/make_golden_gl.py): <= 1e-4 per channel, the tolerance north_star states, one frame at a time and through
+    gsx_render_views."""
+    calls = gl_golden_calls()
+    assert len(calls) >= 18
+    render = hip_render_factory(ctx)
+    flips = 0
+    for cid, xyz, scale, rot, opacity, f_dc, cam, W, H, frame in calls:
+        img = render(xyz, scale, rot, opacity, f_dc, cam, W, H)
+        flips += check_against_gl_frame(img, frame, cid)[1]
+    assert flips <= 2
+    # the dense scene again, both cameras in flight at once (pre_multi_kernel, twin streams)
+    dense = [c for c in calls if c[0].startswith("render_gl_scenes") and len(c[1]) == 4000]
+    assert len(dense) == 2
+    _, xyz, scale, rot, opacity, f_dc, _, W, H, _ = dense[0]
+    ctx.upload_splats(xyz, scale, rot, opacity, f_dc)
+    frames = ctx.render_views([c[6] for c in dense], W, H)
+    for c, img in zip(dense, frames):
+        check_against_gl_frame(img, c[9], c[0] + " (render_views)")
 
 
 @pytest.mark.parametrize("case", render_cases.ALL_CASES, ids=lambda c: c.__name__)
