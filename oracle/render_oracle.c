@@ -20,7 +20,7 @@
  * executed by Mesa llvmpipe (the software OpenGL ES 3.2 of the image, reached through the DRI swrast interface:
  * tools/gl_reference/gl_frames.c, tests/golden/make_golden_gl.py) on the reference's own texture / depthIndex -
  * <= 1e-4 per channel on every pixel except fragments that sit on the discard threshold A = -4, which GL's
- * 1/256-pixel vertex snapping decides (1 pixel in ~80 000 over 124 random frames, profiles/r03/gl_reference_soak.txt).
+ * 1/256-pixel vertex snapping decides (1 pixel in ~50 000 over 128 random frames, profiles/r03/gl_reference_soak.txt).
  * Rounds 1-2 had known-answer tests only.  The SH colour (gsxo_sh_colors) stays "parity unpinned": gs.js reads f_dc only.
  * JavaScript numbers are fp64 and never fused: build with -ffp-contract=off.  GLSL highp float is
  * restated in fp32 without contraction.

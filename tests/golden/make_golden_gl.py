@@ -103,6 +103,9 @@ class GlReference:
         return self.frames(xyz, scale, rot, opacity, f_dc, [cam], W, H)[0]
 
 
+BIG = (40_000, 150_000)
+
+
 def soak(K):
     """Random scenes: how far is oracle/render_oracle.c from the reference's shaders, and how often does a threshold fragment flip?"""
     import importlib
@@ -130,6 +133,12 @@ def soak(K):
             for c in cams[1:]:                                         # pull two cameras towards / into the cloud
                 c["position"] = (np.asarray(c["position"]) * rng.uniform(0.05, 0.8)).tolist()
             jobs.append((xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cams, W, H))
+        for k, n in enumerate(BIG):   # heavy overdraw: tens of thousands of splats on a small frame
+            W, H = 480, 270
+            seed = 0xB16B00 + k
+            xyz = scene.make_positions(n, seed)
+            a = scene.make_splat_attributes(n, seed, sh_degree=0)
+            jobs.append((xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], scene.make_cameras(5, W, H, convention="c2w")[k:k + 2], W, H))
         for xyz, sc, rot, op, fdc, cams, W, H in jobs:
             fr = gl.frames(xyz, sc, rot, op, fdc, cams, W, H)
             for cam, f in zip(cams, fr):
