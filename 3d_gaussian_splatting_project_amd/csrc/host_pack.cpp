@@ -160,6 +160,16 @@ int numa_node_of(const void* addr) {
 
 // the L3 domains of one NUMA node (`want_node`; < 0: the node of the calling thread), each intersected with the
 // process's affinity mask
+// GSX_HOST_AFFINITY: "0" = leave the workers where the scheduler puts them; "node" = bind them to the node's CPUs as one set;
+// anything else (default) = deal them round-robin over the node's L3 domains.  Round 3 measured the three under bench.py's own
+// run, interleaved three times on one box (profiles/r03/affinity_ab.txt): 8.26 / 8.45 / 8.13 ms per step on average, every
+// policy best once - the L3 dealing takes 3-6 steps longer to settle (the scheduler spreads each pair of workers over its CCD's
+// cores only gradually) but holds the lower steady rate when the socket's other tenants are busy.  Default unchanged.
+static bool affinity_per_l3() {
+    const char* e = std::getenv("GSX_HOST_AFFINITY");
+    return !(e && e[0] == 'n');
+}
+
 static std::vector<cpu_set_t> l3_domains(int want_node) {
     std::vector<cpu_set_t> out;
     const char* e = std::getenv("GSX_HOST_AFFINITY");
@@ -210,7 +220,14 @@ Workers::Workers(int threads, int numa_node) : impl_(new Impl), nthreads_(thread
         nthreads_ = impl->nthreads = 1;
         impl->slots = new Slot[1];
     }
-    const std::vector<cpu_set_t> doms = nthreads_ > 1 ? l3_domains(numa_node) : std::vector<cpu_set_t>();
+    std::vector<cpu_set_t> doms = nthreads_ > 1 ? l3_domains(numa_node) : std::vector<cpu_set_t>();
+    if (!affinity_per_l3() && doms.size() > 1) {
+        // policy "node": one set = all of the node's CPUs the process may use; the scheduler places the workers inside it
+        cpu_set_t all;
+        CPU_ZERO(&all);
+        for (const cpu_set_t& d : doms) CPU_OR(&all, &all, &d);
+        doms.assign(1, all);
+    }
     // the caller itself sits in one of the domains (it is not moved); start dealing after it
     size_t first = 0;
     const int cpu = sched_getcpu();
@@ -233,7 +250,7 @@ Workers::Workers(int threads, int numa_node) : impl_(new Impl), nthreads_(thread
             nthreads_ = impl->nthreads = 1;
             break;
         }
-        if (doms.size() > 1) {
+        if (!doms.empty()) {
             const cpu_set_t& dom = doms[(first + (size_t)i) % doms.size()];
             (void)pthread_setaffinity_np(impl->threads.back().native_handle(), sizeof dom, &dom);
         }

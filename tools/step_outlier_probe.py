@@ -15,7 +15,22 @@ n, V, W, H = 3_000_000, 200, 1920, 1080
 pos = scene.make_positions(n, scene.BASE_SEED + 3)
 cams = [pkg.Camera.from_dict(c) for c in scene.make_cameras(V, W, H, convention="w2c")]
 base = [scene.make_segmap(H, W, 150, 3000 + v, cell=4) for v in range(8)]
-segs = [base[v % 8].copy() for v in range(V)]
+how = sys.argv[2] if len(sys.argv) > 2 else "numpy"
+if how == "torch":      # memory of a CPU tensor (what `.cpu().numpy()` of a segmentation network's output is): plain 4 KB pages
+    keep = [torch.from_numpy(base[v % 8]).clone() for v in range(V)]
+    segs = [t.numpy() for t in keep]
+else:                   # numpy's own allocation (np.load of a _segmap.npy): madvise(MADV_HUGEPAGE) above 4 MB
+    segs = [base[v % 8].copy() for v in range(V)]
+
+
+def huge_mb():
+    for line in open("/proc/self/smaps_rollup"):
+        if line.startswith("AnonHugePages"):
+            return int(line.split()[1]) >> 10
+    return -1
+
+
+print("maps allocated by", how, "- AnonHugePages", huge_mb(), "MB of", sum(s_.nbytes for s_ in segs) >> 20, "MB of maps", flush=True)
 out = np.empty(n, np.int32)
 
 
@@ -54,6 +69,11 @@ with pkg.Context(0) as ctx:
         torch.cuda.synchronize()
 
     steps(6, "warm-up")
+    if len(sys.argv) > 3 and sys.argv[3] == "short":
+        steps(14, "back to back")
+        steps(14, "back to back")
+        print("AnonHugePages now", huge_mb(), "MB", flush=True)
+        sys.exit(0)
     for rep in range(2):
         steps(14, "back to back")
         fence(); steps(4, "after a fence")
