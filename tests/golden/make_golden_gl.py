@@ -215,6 +215,17 @@ def main():
             a["scale"][59] = [-12, -12, -12]
             a["scale"][60] = [0.3, 0.3, 0.3] if sid == 0 else [2.5, 2.5, 2.5]   # a large splat / one whose 4*Sigma overflows fp16
             a["scale"][61] = [-20, -20, -19]
+            if sid == 1:   # non-finite attributes as a broken PLY would carry them: what the JS packer and the shaders make of them
+                xyz[100:105, 0] = np.nan
+                xyz[105:110, 1] = np.inf
+                a["scale"][110:115, 2] = np.nan
+                a["scale"][115:120, 0] = np.inf
+                a["scale"][120:125, 0] = -np.inf
+                a["rot"][125:130, 1] = np.nan
+                a["rot"][130:135] = 0.0
+                a["opacity"][135:140] = np.nan
+                a["f_dc"][140:145, 0] = np.nan
+                a["f_dc"][145:150, 2] = np.inf
             cams = scene.make_cameras(V, W, H, convention="c2w")
             if sid == 1:   # a camera INSIDE the cloud: near-plane fade, the 1.2 w cull, the 1024 px axis clamp on real data
                 c = dict(cams[0])
