@@ -253,6 +253,12 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
                                                                                         // kConsumedSlots lines: same-address atomics serialise in one L2 channel
 }
 
+// (Round 3 tried the records through the SCALAR unit instead of LDS: every lane of a tile walks the same list, so list entry and
+// record are wave-uniform; hipcc emits s_load_dword / s_load_dwordx4 for them and the VALU instructions take them as SGPR
+// operands - no LDS, no staging barriers, four records in flight per wave, 94 SGPRs, pixels identical.  Measured at 3 M splats /
+// 1080p: 0.485 ms of blend per view against 0.319, 1256-1261 views/s against 1448-1464 (profiles/r03/blend_scalar_ab.txt): three
+// 64-byte lines per record through a 16 KB scalar cache cost more than the broadcast ds_reads they replace.  Removed.)
+
 // ---- four pixels per thread, one wave per tile ----------------------------------------------------------------
 // A tile that never saturates walks its whole list one dependent splat after the other; what it waits for is
 // latency.  Here a lane owns FOUR pixels (rows y, y+4, y+8, y+12 as two packed pairs): four independent
