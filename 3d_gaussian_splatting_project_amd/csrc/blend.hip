@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
 // order is unchanged (mul, mul, add; no contraction), so `discard` decides exactly as before.
 typedef float f2 __attribute__((ext_vector_type(2)));
 static constexpr int kBlend2Threads = 128;
-static constexpr int kBlend2Chunk = 256;
+static constexpr int kBlend2Chunk = 256;  // (128: +3 % views/s, 512: -20 %; the one-wave kernel below is the default now)
 
 struct Accum2 {
     f2 r, g, b, a;
@@ -265,7 +265,16 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
 // accumulation chains per lane hide that latency, the whole tile is one wave (no barrier partner to wait
 // for), and every staged record is read from LDS once per tile.
 static constexpr int kBlend4Threads = 64;
-static constexpr int kBlend4Chunk = 128;
+// Staging chunk and distance between two opacity votes, measured at 3 M splats / 1080p with four frames in flight
+// (profiles/r03/blend_chunks.txt; views/s, pairs the blend really evaluates per view): a vote per chunk of 256 / 128 / 64 records
+// 1410 / 1476 / 1540 (2.23 M / 2.05 M / 1.77 M pairs); chunk 64 with a vote every 32 / 16 / 8 records 1561-1581 / 1579-1587 /
+// 1575-1583 (1.64 M / 1.58 M / 1.55 M); chunk 128 or 256 with a vote every 16: 1567-1571 / 1548; fetching the next chunk's records into
+// registers while this one is blended: no gain (1533-1540 against 1549-1552 on the same box).  What a tile walks behind the record
+// at which its last pixel saturates is pure waste, and round 2's 256-record chunks of the two-pixel kernel walked 40 % more
+// records than needed.
+static constexpr int kBlend4Chunk = 64;
+static constexpr int kBlend4Group = 16;  // records between two "is the whole tile opaque?" votes (even)
+static_assert(kBlend4Group % 2 == 0 && kBlend4Group >= 2, "the pair loop");
 
 __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ tile_order,
@@ -315,29 +324,34 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
             s2[t] = rec2[id];
         }
         __syncthreads();
-        int k = 0;
-        for (; k + 2 <= cnt; k += 2) {
-            f2 qA[2], qB[2];
+        // the tile is ONE wave: "every pixel opaque" is a wave vote, no barrier - taken every kBlend4Group records, not once per
+        // staged chunk (the records behind the point where the last pixel saturates are pure waste)
+        for (int k0 = 0; k0 < cnt && !opaque; k0 += kBlend4Group) {
+            const int k1 = min(k0 + kBlend4Group, cnt);
+            int k = k0;
+            for (; k + 2 <= k1; k += 2) {
+                f2 qA[2], qB[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                qA[u] = splat_q2(fxp, fyA, s0[k + u], s1[k + u]);
-                qB[u] = splat_q2(fxp, fyB, s0[k + u], s1[k + u]);
-            }
+                for (int u = 0; u < 2; ++u) {
+                    qA[u] = splat_q2(fxp, fyA, s0[k + u], s1[k + u]);
+                    qB[u] = splat_q2(fxp, fyB, s0[k + u], s1[k + u]);
+                }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                accumulate2(accA, qA[u], s1[k + u], s2[k + u]);
-                accumulate2(accB, qB[u], s1[k + u], s2[k + u]);
+                for (int u = 0; u < 2; ++u) {
+                    accumulate2(accA, qA[u], s1[k + u], s2[k + u]);
+                    accumulate2(accB, qB[u], s1[k + u], s2[k + u]);
+                }
             }
+            for (; k < k1; ++k) {
+                blend_one2(accA, fxp, fyA, s0[k], s1[k], s2[k]);
+                blend_one2(accB, fxp, fyB, s0[k], s1[k], s2[k]);
+            }
+            staged += k1 - k0;
+            const float lim = 1.0f - 1.0e-5f;
+            const bool done = (!in[0] || accA.a.x > lim) && (!in[1] || accA.a.y > lim) && (!in[2] || accB.a.x > lim) &&
+                              (!in[3] || accB.a.y > lim);
+            opaque = __all(done) != 0;
         }
-        for (; k < cnt; ++k) {
-            blend_one2(accA, fxp, fyA, s0[k], s1[k], s2[k]);
-            blend_one2(accB, fxp, fyB, s0[k], s1[k], s2[k]);
-        }
-        staged += cnt;
-        const float lim = 1.0f - 1.0e-5f;
-        const bool done = (!in[0] || accA.a.x > lim) && (!in[1] || accA.a.y > lim) && (!in[2] || accB.a.x > lim) &&
-                          (!in[3] || accB.a.y > lim);
-        opaque = __syncthreads_and(done) != 0;
         if (opaque) break;
     }
     if (opaque && threadIdx.x == 0) sat[tile] = 1;

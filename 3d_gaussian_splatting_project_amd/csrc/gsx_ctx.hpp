@@ -141,7 +141,7 @@ struct Ctx {
     int opt_slabs = 1;         // see Ctx::slabs (takes effect at the next vote_begin)
     int opt_local_codes = 0;   // see Ctx::local_codes
     int opt_lds_batch = 0;     // read a chunk's LDS counters in one round trip (repeats resolved in registers)
-    int opt_blend_pk2 = 1;     // rasterizer: two pixels per thread, packed fp32 maths
+    int opt_blend_pk2 = 2;     // rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four, one wave per tile (default since round 3)
     int opt_exact_cull = 0;    // rasterizer: keep only the tiles the splat's ellipse really reaches (pairs -23 %; the test costs more than the sort saves)
     int opt_tile_lpt = 0;      // rasterizer: launch the tiles with the longest lists first (blend -3 %, but net 0)
     int opt_seg_tiled = 1;     // store seg maps as 16x8-pixel tiles of 128 B

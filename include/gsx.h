@@ -118,7 +118,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *   "labels_u8"    (default 1)  labels leave the device as one byte each (label + 1) and are widened on the host
  *                               (gsx_vote_finalize); 0 = int32 over the link
  *   "exchange_slabs" / "exchange_local"  plane layout of exchange protocol v2, see gsx_vote_slab_reduce
- *   "blend_pk2"    (default 1)  rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four (one wave per tile)
+ *   "blend_pk2"    (default 2)  rasterizer: 0 = one pixel per thread, 1 = two (packed fp32), 2 = four (one wave per tile,
+ *                               staging chunks of 64 records, the "tile opaque" vote every 16)
  *   "render_phases" (default 2) rasterizer: a frame is binned, sorted and blended front to back in this many DEPTH
  *                               PHASES (1..8); a phase skips the tiles the earlier ones left opaque (1 - alpha <
  *                               1e-5 on every pixel), so a dense scene sorts a few times the (tile, splat) pairs the

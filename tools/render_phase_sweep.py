@@ -19,7 +19,8 @@ with pkg.Context(0) as c:
              {"render_phases": 2, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 3}, {"exact_cull": 1},
              {"render_phases": 3, "exact_cull": 1}, {"tile_lpt": 1}, {})
     if len(sys.argv) > 1 and sys.argv[1] == "ab":      # a clean A/B of the two candidates, interleaved three times
-        sweep = ({}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3}) * 3 + ({},)
+        sweep = ({}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3}, {"render_phases": 2, "render_phase_ratio": 3},
+                 {"render_phases": 2, "render_phase_ratio": 6}, {"tile_lpt": 1}) * 2 + ({},)
     if len(sys.argv) > 1 and sys.argv[1] == "blend":   # blend kernels: 1 = two pixels per thread, 2 = four (one wave per tile)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2}) * 3
         for mode in (1, 2):
@@ -31,8 +32,10 @@ with pkg.Context(0) as c:
             cnt, ms = c.profile_get("render_blend")
             c.profile(False)
             print(f"blend_pk2={mode}: render_blend {ms / 8:.4f} ms per view ({cnt} launches)", flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
+        sweep = ({"blend_pk2": 1}, {"blend_pk2": 2})
     for opts in sweep:
-        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 1}
+        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2}
         base.update(opts)
         for k, v in base.items():
             c.set_option(k, v)
