@@ -367,11 +367,15 @@ __device__ __forceinline__ PreGeom pre_geom(const uint4 t0, const uint4 t1, cons
         const float big = 3.0e38f;
         if (!(m2 > 0.0f) || !(n2 > 0.0f) || !(m2 < big) || !(n2 < big) || !(fabsf(wcx) < big) || !(fabsf(wcy) < big)) drawn = false;
         if (drawn) {
-            // pixels whose centre can satisfy |vPosition| <= 2: the ellipse's bounding box, +1 px of slack
-            const float ex = sqrtf(mx * mx + nx * nx) + 1.0f, ey = sqrtf(my * my + ny * ny) + 1.0f;
+            // pixels whose CENTRE can satisfy |vPosition| <= 2: the bounding box of the ellipse with the orthogonal half-axes m
+            // and n (vPosition = (2 d.m/|m|^2, 2 d.n/|n|^2)), i.e. |x + 0.5 - cx| <= sqrt(mx^2 + nx^2), + 1/64 px for the fp32
+            // rounding of the per-pixel evaluation (which is good to ~1e-6 of the extent; cx itself to 1.2e-4 px at 1920).
+            // (Rounds 1-2 took a whole pixel of slack and floor() on both sides: 1.5 px too wide on every side, i.e. one more
+            // tile column or row for every sixth splat - 12 % more (tile, splat) pairs to bin, sort and stage.)
+            const float ex = sqrtf(mx * mx + nx * nx) + 0.015625f, ey = sqrtf(my * my + ny * ny) + 0.015625f;
             const float top = u.H - wcy;  // image row coordinate of the centre
-            int x0 = (int)floorf(fminf(fmaxf(wcx - ex, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex, -1.0f), u.W));
-            int y0 = (int)floorf(fminf(fmaxf(top - ey, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey, -1.0f), u.H));
+            int x0 = (int)ceilf(fminf(fmaxf(wcx - ex - 0.5f, -1.0f), u.W)), x1 = (int)floorf(fminf(fmaxf(wcx + ex - 0.5f, -1.0f), u.W));
+            int y0 = (int)ceilf(fminf(fmaxf(top - ey - 0.5f, -1.0f), u.H)), y1 = (int)floorf(fminf(fmaxf(top + ey - 0.5f, -1.0f), u.H));
             x0 = max(x0, 0);
             y0 = max(y0, 0);
             x1 = min(x1, (int)u.W - 1);
