@@ -19,8 +19,8 @@ with pkg.Context(0) as c:
              {"render_phases": 2, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 3}, {"exact_cull": 1},
              {"render_phases": 3, "exact_cull": 1}, {"tile_lpt": 1}, {})
     if len(sys.argv) > 1 and sys.argv[1] == "ab":      # a clean A/B of the two candidates, interleaved three times
-        sweep = ({}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3}, {"render_phases": 2, "render_phase_ratio": 3},
-                 {"render_phases": 2, "render_phase_ratio": 6}, {"tile_lpt": 1}) * 2 + ({},)
+        sweep = ({}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3}, {"render_phases": 3, "render_phase_ratio": 5},
+                 {"render_phases": 4, "render_phase_ratio": 3}, {"render_phases": 4, "render_phase_ratio": 2}, {"tile_lpt": 1}) * 2 + ({},)
     if len(sys.argv) > 1 and sys.argv[1] == "blend":   # blend kernels: 1 = two pixels per thread, 2 = four (one wave per tile)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2}) * 3
         for mode in (1, 2):
