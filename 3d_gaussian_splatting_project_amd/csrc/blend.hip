@@ -292,21 +292,23 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * kTile + (threadIdx.x & (kTile - 1));
-    const int row = ty * kTile + (threadIdx.x >> 4);  // rows row, row+4, row+8, row+12
+    const int row = ty * kTile + (threadIdx.x >> 4);  // rows row, row+4 (pair A: the tile's upper half), row+8, row+12 (pair B: the lower half)
+    // A splat that reaches only one half of the tile skips the other pair's accumulation for the whole wave (the `if` of
+    // accumulate2 is then false in every lane); with the rows interleaved (A = row, row+8) both pairs spanned the tile.
     const float fxp = (float)px + 0.5f;
     f2 fyA, fyB;
     fyA.x = (float)H - ((float)row + 0.5f);
-    fyA.y = (float)H - ((float)(row + 8) + 0.5f);
-    fyB.x = (float)H - ((float)(row + 4) + 0.5f);
+    fyA.y = (float)H - ((float)(row + 4) + 0.5f);
+    fyB.x = (float)H - ((float)(row + 8) + 0.5f);
     fyB.y = (float)H - ((float)(row + 12) + 0.5f);
-    const bool in[4] = {px < W && row < H, px < W && row + 8 < H, px < W && row + 4 < H, px < W && row + 12 < H};
+    const bool in[4] = {px < W && row < H, px < W && row + 4 < H, px < W && row + 8 < H, px < W && row + 12 < H};
     const int2 range = ranges[tile];
     if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 accA{}, accB{};
     if (!first) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 p0 = in[0] ? image[(size_t)row * W + px] : z, p1 = in[1] ? image[(size_t)(row + 8) * W + px] : z;
-        const float4 p2 = in[2] ? image[(size_t)(row + 4) * W + px] : z, p3 = in[3] ? image[(size_t)(row + 12) * W + px] : z;
+        const float4 p0 = in[0] ? image[(size_t)row * W + px] : z, p1 = in[1] ? image[(size_t)(row + 4) * W + px] : z;
+        const float4 p2 = in[2] ? image[(size_t)(row + 8) * W + px] : z, p3 = in[3] ? image[(size_t)(row + 12) * W + px] : z;
         accA.r.x = p0.x, accA.g.x = p0.y, accA.b.x = p0.z, accA.a.x = p0.w;
         accA.r.y = p1.x, accA.g.y = p1.y, accA.b.y = p1.z, accA.a.y = p1.w;
         accB.r.x = p2.x, accB.g.x = p2.y, accB.b.x = p2.z, accB.a.x = p2.w;
@@ -366,8 +368,8 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
         }
     }
     if (in[0]) image[(size_t)row * W + px] = make_float4(accA.r.x, accA.g.x, accA.b.x, accA.a.x);
-    if (in[1]) image[(size_t)(row + 8) * W + px] = make_float4(accA.r.y, accA.g.y, accA.b.y, accA.a.y);
-    if (in[2]) image[(size_t)(row + 4) * W + px] = make_float4(accB.r.x, accB.g.x, accB.b.x, accB.a.x);
+    if (in[1]) image[(size_t)(row + 4) * W + px] = make_float4(accA.r.y, accA.g.y, accA.b.y, accA.a.y);
+    if (in[2]) image[(size_t)(row + 8) * W + px] = make_float4(accB.r.x, accB.g.x, accB.b.x, accB.a.x);
     if (in[3]) image[(size_t)(row + 12) * W + px] = make_float4(accB.r.y, accB.g.y, accB.b.y, accB.a.y);
     if (threadIdx.x == 0 && staged) atomicAdd(consumed + (blockIdx.x & (kConsumedSlots - 1)) * 16, (unsigned long long)staged);  // statistics, spread over
                                                                                         // kConsumedSlots lines: same-address atomics serialise in one L2 channel
