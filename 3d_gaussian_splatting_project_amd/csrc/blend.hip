@@ -81,9 +81,7 @@ __global__ __launch_bounds__(256) void tile_order_key_kernel(const int2* __restr
 __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __restrict__ ranges,
                                                               const uint32_t* __restrict__ tile_order,
                                                               const uint32_t* __restrict__ vals,
-                                                              const float4* __restrict__ rec0,
-                                                              const float4* __restrict__ rec1,
-                                                              const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                              const float4* __restrict__ rec, int W, int H, int tiles_x,
                                                               const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                               unsigned long long* __restrict__ consumed,
                                                               float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
@@ -112,9 +110,9 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
         __syncthreads();
         if ((int)threadIdx.x < cnt) {
             const uint32_t id = vals[base + threadIdx.x];
-            s0[threadIdx.x] = rec0[id];
-            s1[threadIdx.x] = rec1[id];
-            s2[threadIdx.x] = rec2[id];
+            s0[threadIdx.x] = rec[3 * (size_t)id];
+            s1[threadIdx.x] = rec[3 * (size_t)id + 1];
+            s2[threadIdx.x] = *reinterpret_cast<const float2*>(rec + 3 * (size_t)id + 2);
         }
         __syncthreads();
         for (int k = 0; k < cnt; ++k) blend_one(acc, fxp, fyp, s0[k], s1[k], s2[k]);
@@ -129,9 +127,9 @@ __global__ __launch_bounds__(kBlendThreads) void blend_kernel(const int2* __rest
     // last, once per dropped splat (gs.js:453-457 + 1076-1077, 1609)
     const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
-        const float4 r0 = rec0[0];
-        const float4 r1 = rec1[0];
-        const float2 r2 = rec2[0];
+        const float4 r0 = rec[0];
+        const float4 r1 = rec[1];
+        const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);
         for (int k = 0; k < nd; ++k) blend_one(acc, fxp, fyp, r0, r1, r2);
     }
     if (inside) image[(size_t)py * W + px] = make_float4(acc.r, acc.g, acc.b, acc.a);
@@ -183,9 +181,7 @@ __device__ __forceinline__ void blend_one2(Accum2& acc, float fxp, f2 fyp, const
 __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ tile_order,
                                                                 const uint32_t* __restrict__ vals,
-                                                                const float4* __restrict__ rec0,
-                                                                const float4* __restrict__ rec1,
-                                                                const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                                const float4* __restrict__ rec, int W, int H, int tiles_x,
                                                                 const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                                 unsigned long long* __restrict__ consumed,
                                                                 float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
@@ -218,9 +214,9 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += kBlend2Threads) {
             const uint32_t id = vals[base + t];
-            s0[t] = rec0[id];
-            s1[t] = rec1[id];
-            s2[t] = rec2[id];
+            s0[t] = rec[3 * (size_t)id];
+            s1[t] = rec[3 * (size_t)id + 1];
+            s2[t] = *reinterpret_cast<const float2*>(rec + 3 * (size_t)id + 2);
         }
         __syncthreads();
         // the splats are independent up to the accumulation: evaluate 4 quadratics at once (4 dependency chains
@@ -242,9 +238,9 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     if (opaque && threadIdx.x == 0) sat[tile] = 1;
     const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
-        const float4 r0 = rec0[0];
-        const float4 r1 = rec1[0];
-        const float2 r2 = rec2[0];
+        const float4 r0 = rec[0];
+        const float4 r1 = rec[1];
+        const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);
         for (int k = 0; k < nd; ++k) blend_one2(acc, fxp, fyp, r0, r1, r2);
     }
     if (in0) image[(size_t)py0 * W + px] = make_float4(acc.r.x, acc.g.x, acc.b.x, acc.a.x);
@@ -279,9 +275,7 @@ static_assert(kBlend4Group % 2 == 0 && kBlend4Group >= 2, "the pair loop");
 __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ tile_order,
                                                                 const uint32_t* __restrict__ vals,
-                                                                const float4* __restrict__ rec0,
-                                                                const float4* __restrict__ rec1,
-                                                                const float2* __restrict__ rec2, int W, int H, int tiles_x,
+                                                                const float4* __restrict__ rec, int W, int H, int tiles_x,
                                                                 const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                                 unsigned long long* __restrict__ consumed,
                                                                 float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
@@ -321,9 +315,9 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
         __syncthreads();
         for (int t = threadIdx.x; t < cnt; t += kBlend4Threads) {
             const uint32_t id = vals[base + t];
-            s0[t] = rec0[id];
-            s1[t] = rec1[id];
-            s2[t] = rec2[id];
+            s0[t] = rec[3 * (size_t)id];
+            s1[t] = rec[3 * (size_t)id + 1];
+            s2[t] = *reinterpret_cast<const float2*>(rec + 3 * (size_t)id + 2);
         }
         __syncthreads();
         // the tile is ONE wave: "every pixel opaque" is a wave vote, no barrier - taken every kBlend4Group records, not once per
@@ -359,9 +353,9 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     if (opaque && threadIdx.x == 0) sat[tile] = 1;
     const int nd = (last && n > 0) ? *dropped : 0;
     if (nd > 0) {
-        const float4 r0 = rec0[0];
-        const float4 r1 = rec1[0];
-        const float2 r2 = rec2[0];
+        const float4 r0 = rec[0];
+        const float4 r1 = rec[1];
+        const float2 r2 = *reinterpret_cast<const float2*>(rec + 2);
         for (int k = 0; k < nd; ++k) {
             blend_one2(accA, fxp, fyA, r0, r1, r2);
             blend_one2(accB, fxp, fyB, r0, r1, r2);
@@ -393,15 +387,15 @@ int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int ti
     ProfScope ps(c, "render_blend");
     if (c->opt_blend_pk2 == 2) {
         hipLaunchKernelGGL(blend4_kernel, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
-                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
                            c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     } else if (c->opt_blend_pk2) {
         hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
-                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
                            c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     } else {
         hipLaunchKernelGGL(blend_kernel, dim3(ntiles), dim3(kBlendThreads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
-                           c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), c->r_rec2.as<float2>(), W, H, tiles_x, dropped_dev,
+                           c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
                            c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
     }
     GSX_HIP(c, hipGetLastError());

@@ -257,13 +257,13 @@ struct Ctx {
     DevBuf r_image;                      // float4[H][W] of the last view
     int r_W = 0, r_H = 0;
     DevBuf r_ranges, r_small, r_scan;
-    DevBuf r_depth, r_bucket, r_rect, r_count, r_offset, r_rec0, r_rec1, r_rec2;
+    DevBuf r_depth, r_bucket, r_rect, r_count, r_offset, r_rec;
     DevBuf r_pre;                        // int[4]: min depth, max depth, splat 0's tile rectangle (written by the pre pass)
     // gsx_render_views with several frames in flight: ONE pre pass per group of frames (pre_multi_kernel) writes the per-view
     // records of all of them; a frame's records live in one of three rotating sets so that the pass for group g + 1 can run
     // while the frames of group g (and stragglers of g - 1) still read theirs
     struct PreSet {
-        DevBuf depth, rect, rec0, rec1, rec2, pre;
+        DevBuf depth, rect, rec, pre;
     };
     static constexpr int kPreSets = 3;
     PreSet r_sets[kPreSets];

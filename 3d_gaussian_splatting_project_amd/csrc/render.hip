@@ -14,7 +14,8 @@
 // HBM layout
 //   tex        uint4[2n]   the viewer's RGBA32UI texel pairs: [x y z label][h01 h23 h45 rgba8], importance order
 //   buffer     u8[32n]     the viewer's .splat rows (pos, exp(scale), rgba8, quat8)
-//   rec0/1/2   float4,float4,float2 per splat per view: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a)
+//   rec        3 x float4 per splat per view, ONE 48-byte record: (cx, cy, g0x, g0y) (g1x, g1y, r, g) (b, a, -, -).  (Rounds 1-2 and
+//              most of round 3 kept three arrays: a blend gather then touched three 64-byte segments per record instead of 1.5.)
 //   keys/vals  u32[P]      (tile, splat) pairs emitted in depth order, P = sum of tiles touched
 //   ranges     int2[tiles] [start, end) into the sorted pairs
 #include <hip/hip_runtime.h>
@@ -458,8 +459,7 @@ __device__ __forceinline__ void depth_range_to(int lo, int hi, int* __restrict__
 __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex, long long n, ViewUniforms u,
                                                    const float* __restrict__ sh_coef, int sh_deg, float cpx, float cpy, float cpz,
                                                    int* __restrict__ depth, int* __restrict__ pre,
-                                                   float4* __restrict__ rec0, float4* __restrict__ rec1,
-                                                   float2* __restrict__ rec2, uint32_t* __restrict__ tile_rect) {
+                                                   float4* __restrict__ rec, uint32_t* __restrict__ tile_rect) {
     __shared__ int slo[4], shi[4];
     int lo = 2147483647, hi = -2147483647 - 1;
     // grid-stride: the launch is capped at 2048 workgroups, i.e. 4096 same-address atomics per frame (one pair per
@@ -471,9 +471,9 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
         depth[i] = o.depth;
         lo = min(lo, o.depth);
         hi = max(hi, o.depth);
-        rec0[i] = o.r0;
-        rec1[i] = o.r1;
-        rec2[i] = o.r2;
+        rec[3 * i] = o.r0;
+        rec[3 * i + 1] = o.r1;
+        rec[3 * i + 2] = make_float4(o.r2.x, o.r2.y, 0.f, 0.f);
         tile_rect[i] = o.rect;
         if (i == 0) pre[2] = (int)o.rect;
     }
@@ -500,9 +500,7 @@ struct PreMultiArgs {
     float cam[kPreViews][3];
     int* depth[kPreViews];
     int* pre[kPreViews];
-    float4* rec0[kPreViews];
-    float4* rec1[kPreViews];
-    float2* rec2[kPreViews];
+    float4* rec[kPreViews];
     uint32_t* rect[kPreViews];
     int nv;
 };
@@ -533,7 +531,7 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
             __builtin_nontemporal_store(g.depth, &a.depth[v][i]);  // streaming stores: the records are not read again here
             lo[v] = min(lo[v], g.depth);
             hi[v] = max(hi[v], g.depth);
-            nt_store4(&a.rec0[v][i], g.r0);
+            a.rec[v][3 * i] = g.r0;  // (ordinary stores: the three 16-byte pieces of a record meet in the L2 before they leave it)
             __builtin_nontemporal_store(g.rect, &a.rect[v][i]);
             if (i == 0) a.pre[v][2] = (int)g.rect;
             g1x[v] = g.g1x, g1y[v] = g.g1y, fade[v] = g.fade;
@@ -579,9 +577,8 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
                 r1 = make_float4(g1x[v], g1y[v], col[0], col[1]);
                 r2 = make_float2(col[2], col[3]);
             }
-            nt_store4(&a.rec1[v][i], r1);
-            __builtin_nontemporal_store(r2.x, &a.rec2[v][i].x);
-            __builtin_nontemporal_store(r2.y, &a.rec2[v][i].y);
+            a.rec[v][3 * i + 1] = r1;
+            a.rec[v][3 * i + 2] = make_float4(r2.x, r2.y, 0.f, 0.f);
         }
     }
 #pragma unroll
@@ -697,8 +694,8 @@ __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restri
 // COUNT and EMIT run the same tests on the same data (sat is not written in between), so the slots are exact.
 template <bool EMIT>
 __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, const uint32_t* __restrict__ by_depth,
-                                                   const uint32_t* __restrict__ tile_rect, const float4* __restrict__ rec0,
-                                                   const float4* __restrict__ rec1, float H, int tiles_x, int exact,
+                                                   const uint32_t* __restrict__ tile_rect, const float4* __restrict__ rec,
+                                                   float H, int tiles_x, int exact,
                                                    const uint8_t* __restrict__ sat, uint32_t* __restrict__ count_out,
                                                    const uint32_t* __restrict__ offset, uint32_t* __restrict__ keys,
                                                    uint32_t* __restrict__ vals, const unsigned long long* __restrict__ total_dev,
@@ -732,8 +729,8 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
     const bool test = exact && area > 1u;  // a one-tile rectangle holds the centre's tile or touches it by construction
     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
     if (test) {
-        r0 = rec0[i];
-        r1 = rec1[i];
+        r0 = rec[3 * (size_t)i];
+        r1 = rec[3 * (size_t)i + 1];
     }
     const uint32_t my_off = EMIT && live ? offset[j - j0] : 0u;
     uint32_t kept_run = 0;  // kept candidates of MY splat in the rounds so far
@@ -949,9 +946,7 @@ static int ensure_pre_set(Ctx* c, Ctx::PreSet& ps, long long n) {
     const size_t n4 = 4 * (size_t)n;
     GSX_HIP(c, ps.depth.ensure(n4));
     GSX_HIP(c, ps.rect.ensure(n4));
-    GSX_HIP(c, ps.rec0.ensure(16 * (size_t)n));
-    GSX_HIP(c, ps.rec1.ensure(16 * (size_t)n));
-    GSX_HIP(c, ps.rec2.ensure(8 * (size_t)n));
+    GSX_HIP(c, ps.rec.ensure(48 * (size_t)n));
     GSX_HIP(c, ps.pre.ensure(16));
     return GSX_OK;
 }
@@ -1030,9 +1025,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         if (rcs) return rcs;
         c->r_depth.alias(ps.depth);
         c->r_rect.alias(ps.rect);
-        c->r_rec0.alias(ps.rec0);
-        c->r_rec1.alias(ps.rec1);
-        c->r_rec2.alias(ps.rec2);
+        c->r_rec.alias(ps.rec);
         c->r_pre.alias(ps.pre);
     }
     GSX_HIP(c, c->r_bucket.ensure(n4));
@@ -1070,8 +1063,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             ProfScope ps(c, "render_pre");
             hipLaunchKernelGGL(pre_kernel, dim3(std::min<unsigned>(grid_for(n), 2048u)), dim3(kRB), 0, c->stream, c->r_tex.as<uint4>(), n, u,
                                c->r_sh_on ? c->r_shc.as<float>() : nullptr, c->r_sh_deg, (float)cam->p[0], (float)cam->p[1],
-                               (float)cam->p[2], c->r_depth.as<int>(), c->r_pre.as<int>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(),
-                               c->r_rec2.as<float2>(), c->r_rect.as<uint32_t>());
+                               (float)cam->p[2], c->r_depth.as<int>(), c->r_pre.as<int>(), c->r_rec.as<float4>(),
+                               c->r_rect.as<uint32_t>());
         }
         {
             ProfScope ps(c, "render_bucket");
@@ -1097,7 +1090,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                 {
                     ProfScope ps(c, "render_bin_count");
                     hipLaunchKernelGGL(bin_kernel<false>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
-                                       c->r_rect.as<uint32_t>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), (float)H, tiles_x,
+                                       c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, tiles_x,
                                        c->opt_exact_cull, sat, c->r_count.as<uint32_t>(), (const uint32_t*)nullptr,
                                        (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
                 }
@@ -1107,7 +1100,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                 {
                     ProfScope ps(c, "render_bin_emit");
                     hipLaunchKernelGGL(bin_kernel<true>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
-                                       c->r_rect.as<uint32_t>(), c->r_rec0.as<float4>(), c->r_rec1.as<float4>(), (float)H, tiles_x,
+                                       c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, tiles_x,
                                        c->opt_exact_cull, sat, (uint32_t*)nullptr, c->r_offset.as<uint32_t>(),
                                        c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap);
                 }
@@ -1213,11 +1206,11 @@ void render_release_twin(Ctx* c) {
         if (!t) continue;
         (void)hipStreamSynchronize(t->stream);
         for (DevBuf* b : {&t->r_tex, &t->r_shc, &t->r_image, &t->r_ranges, &t->r_small, &t->r_scan, &t->r_depth, &t->r_bucket, &t->r_rect,
-                          &t->r_count, &t->r_offset, &t->r_rec0, &t->r_rec1, &t->r_rec2, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
+                          &t->r_count, &t->r_offset, &t->r_rec, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
                           &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist, &t->r_pre})
             b->release();
         for (Ctx::PreSet& ps : t->r_sets)
-            for (DevBuf* b : {&ps.depth, &ps.rect, &ps.rec0, &ps.rec1, &ps.rec2, &ps.pre}) b->release();
+            for (DevBuf* b : {&ps.depth, &ps.rect, &ps.rec, &ps.pre}) b->release();
         if (!t->stream_borrowed) (void)hipStreamDestroy(t->stream);
         t->stream = nullptr;
         delete t;
@@ -1288,9 +1281,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             for (int k = 0; k < 3; ++k) a.cam[v][k] = (float)cam->p[k];
             a.depth[v] = ps.depth.as<int>();
             a.pre[v] = ps.pre.as<int>();
-            a.rec0[v] = ps.rec0.as<float4>();
-            a.rec1[v] = ps.rec1.as<float4>();
-            a.rec2[v] = ps.rec2.as<float2>();
+            a.rec[v] = ps.rec.as<float4>();
             a.rect[v] = ps.rect.as<uint32_t>();
             GSX_HIP(c, hipMemcpyAsync(ps.pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
         }
