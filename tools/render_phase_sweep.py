@@ -34,6 +34,8 @@ with pkg.Context(0) as c:
             cnt, ms = c.profile_get("render_blend")
             c.profile(False)
             print(f"blend_pk2={mode}: render_blend {ms / 8:.4f} ms per view ({cnt} launches)", flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "cull":    # bounding-box binning against the exact ellipse test, interleaved
+        sweep = ({}, {"exact_cull": 1}) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2})
     for opts in sweep:
