@@ -67,7 +67,7 @@ def hip_render_factory(ctx):
     return render
 
 
-def test_frames_match_the_reference_shaders_run_on_llvmpipe(ctx):
+def test_frames_match_the_reference_shaders_run_on_llvmpipe(ctx, gsx):
     """The HIP rasterizer, from raw 3DGS attributes, against the frames of the reference's OWN vertex + fragment shaders and blend
     state (gs.js:661-800, 1033-1038, 1608-1609) executed by Mesa llvmpipe on the reference's own texture / depthIndex
     (tests/golden/make_golden_gl.py): <= 1e-4 per channel, the tolerance north_star states, one frame at a time and through
@@ -88,6 +88,15 @@ def test_frames_match_the_reference_shaders_run_on_llvmpipe(ctx):
     frames = ctx.render_views([c[6] for c in dense], W, H)
     for c, img in zip(dense, frames):
         check_against_gl_frame(img, c[9], c[0] + " (render_views)")
+    # every blend kernel, bounding-box and exact binning, one to three depth phases: the same frames
+    for opts in ({"blend_pk2": 0}, {"blend_pk2": 1, "exact_cull": 1}, {"blend_pk2": 2, "exact_cull": 1, "render_phases": 3},
+                 {"blend_pk2": 1, "render_phases": 1}, {"blend_pk2": 2, "tile_lpt": 1, "render_phase_ratio": 2}):
+        with gsx.Context(0) as c2:
+            for k, v in opts.items():
+                c2.set_option(k, v)
+            c2.upload_splats(xyz, scale, rot, opacity, f_dc)
+            for c in dense:
+                check_against_gl_frame(c2.render_view(c[6], W, H), c[9], f"{c[0]} {opts}")
 
 
 @pytest.mark.parametrize("case", render_cases.ALL_CASES, ids=lambda c: c.__name__)
