@@ -147,7 +147,7 @@ def render_leg(pkg, ctx, args, W, H):
             "blend_roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
                                "algorithmic_bytes": int(alg),
-                               "note": "blend is fp32-VALU bound at 16x16 tiles (counters: profiles/r03/derived_r03d.json, derived_r03d.json: traffic = 1.5 x these bytes); see DESIGN.md"}}
+                               "note": "blend is fp32-VALU bound at 16x16 tiles (counters: profiles/r03/derived_r03d.json: traffic = 1.5 x these bytes); see DESIGN.md"}}
 
 
 def cpu_model():
