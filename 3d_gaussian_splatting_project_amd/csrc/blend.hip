@@ -273,6 +273,12 @@ static constexpr int kBlend4Chunk = 64;
 static constexpr int kBlend4Group = 16;  // records between two "is the whole tile opaque?" votes (even)
 static_assert(kBlend4Group % 2 == 0 && kBlend4Group >= 2, "the pair loop");
 
+// BIN32 (option render_bin32): the pairs are sorted by 32x32-pixel bin and a list entry's top four bits name the bin's tiles the
+// splat was binned for (render.hip: bin_kernel).  Workgroup b is tile (b & 3) of bin b >> 2; it walks the BIN's list 256 entries
+// at a time, keeps the entries whose mask has its bit (four coalesced loads and four ballots, compacted in list order into
+// `ids`) and stages the records of those 64 at a time as before: the same splats in the same order as its own list would hold.
+static constexpr int kBlend4Super = 256;
+template <bool BIN32>
 __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __restrict__ ranges,
                                                                 const uint32_t* __restrict__ tile_order,
                                                                 const uint32_t* __restrict__ vals,
@@ -280,12 +286,26 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
                                                                 const int* __restrict__ dropped, const int* __restrict__ pre, long long n,
                                                                 unsigned long long* __restrict__ consumed,
                                                                 float4* __restrict__ image, uint8_t* __restrict__ sat, int first,
-                                                                int last) {
+                                                                int last, int bins_x, int tiles_y) {
     __shared__ float4 s0[kBlend4Chunk];
     __shared__ float4 s1[kBlend4Chunk];
     __shared__ float2 s2[kBlend4Chunk];
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    __shared__ uint32_t ids[BIN32 ? kBlend4Super + kBlend4Chunk : 1];
+    int tile, tx, ty, list;
+    uint32_t my_bit = 0u;
+    if (BIN32) {
+        list = (int)(blockIdx.x >> 2);
+        const int sub = (int)(blockIdx.x & 3u);
+        tx = 2 * (list % bins_x) + (sub & 1);
+        ty = 2 * (list / bins_x) + (sub >> 1);
+        if (tx >= tiles_x || ty >= tiles_y) return;  // the frame's last column / row of bins may be half empty
+        tile = (int)blockIdx.x;                      // index of the tile's opacity byte: bin * 4 + bit
+        my_bit = 1u << (28 + sub);
+    } else {
+        tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;
+        tx = tile % tiles_x, ty = tile / tiles_x;
+        list = tile;
+    }
     const int px = tx * kTile + (threadIdx.x & (kTile - 1));
     const int row = ty * kTile + (threadIdx.x >> 4);  // rows row, row+4 (pair A: the tile's upper half), row+8, row+12 (pair B: the lower half)
     // A splat that reaches only one half of the tile skips the other pair's accumulation for the whole wave (the `if` of
@@ -297,7 +317,7 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     fyB.x = (float)H - ((float)(row + 8) + 0.5f);
     fyB.y = (float)H - ((float)(row + 12) + 0.5f);
     const bool in[4] = {px < W && row < H, px < W && row + 4 < H, px < W && row + 8 < H, px < W && row + 12 < H};
-    const int2 range = ranges[tile];
+    const int2 range = ranges[list];
     if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 accA{}, accB{};
     if (!first) {
@@ -311,8 +331,36 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     }
     int staged = 0;
     bool opaque = false;
-    for (int base = range.x; base < range.y; base += kBlend4Chunk) {
-        const int cnt = min(kBlend4Chunk, range.y - base);
+    const unsigned long long lane_lt = (1ull << threadIdx.x) - 1ull;
+    // BIN32: `ids` buffers this tile's entries (have of them) until 64 are there or the bin's list ends, so that the staged
+    // chunks - and with them the records at which the opacity votes fall - are those of the tile's own list: bit-identical frames.
+    int have = 0, sbase = range.x;
+    for (;;) {
+        if (BIN32) {
+            while (have < kBlend4Chunk && sbase < range.y) {  // this tile's entries among the next 256 of the bin's list
+                uint32_t v[kBlend4Super / kBlend4Threads];
+#pragma unroll
+                for (int j = 0; j < kBlend4Super / kBlend4Threads; ++j) {
+                    const int e = sbase + j * kBlend4Threads + (int)threadIdx.x;
+                    v[j] = e < range.y ? vals[e] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < kBlend4Super / kBlend4Threads; ++j) {
+                    const bool mine = (v[j] & my_bit) != 0u;
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) ids[have + __popcll(m & lane_lt)] = v[j] & 0x0fffffffu;
+                    have += __popcll(m);
+                }
+                sbase += kBlend4Super;
+            }
+        } else {
+            have = min(kBlend4Chunk, range.y - sbase);
+        }
+        if (have <= 0) break;
+        const bool tail = sbase >= range.y;  // (BIN32) nothing left to fetch: a short last chunk is due
+        int pos = 0;
+        do {
+        const int cnt = min(kBlend4Chunk, have - pos);
         __syncthreads();
         // A lane stages one record - and first asks whether its ellipse reaches this tile at all (the list holds the tiles of the
         // ellipse's BOUNDING BOX: a sixth of the pairs never produce a fragment).  One lane's ~110 instructions spare the whole
@@ -324,7 +372,7 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
         float4 a0, a1;
         float2 a2;
         if ((int)threadIdx.x < cnt) {
-            const uint32_t id = vals[base + threadIdx.x];
+            const uint32_t id = BIN32 ? ids[pos + threadIdx.x] : vals[sbase + threadIdx.x];
             a0 = rec[3 * (size_t)id];
             a1 = rec[3 * (size_t)id + 1];
             a2 = *reinterpret_cast<const float2*>(rec + 3 * (size_t)id + 2);
@@ -332,7 +380,7 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
         }
         const unsigned long long kept = __ballot(keep);
         if (keep) {
-            const int slot = __popcll(kept & ((1ull << threadIdx.x) - 1ull));
+            const int slot = __popcll(kept & lane_lt);
             s0[slot] = a0;
             s1[slot] = a1;
             s2[slot] = a2;
@@ -367,7 +415,20 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
                               (!in[3] || accB.a.y > lim);
             opaque = __all(done) != 0;
         }
+        pos += cnt;
+        } while (BIN32 && !opaque && (have - pos >= kBlend4Chunk || (tail && have > pos)));
         if (opaque) break;
+        if (BIN32) {  // the entries behind the last full chunk move to the front
+            const int left = have - pos;
+            __syncthreads();
+            const uint32_t keep_id = (int)threadIdx.x < left ? ids[pos + threadIdx.x] : 0u;
+            __syncthreads();
+            if ((int)threadIdx.x < left) ids[threadIdx.x] = keep_id;
+            have = left;
+            if (left == 0 && tail) break;
+        } else {
+            sbase += kBlend4Chunk;
+        }
     }
     if (opaque && threadIdx.x == 0) sat[tile] = 1;
     const int nd = (last && n > 0) ? *dropped : 0;
@@ -392,7 +453,7 @@ int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int ti
                  unsigned long long* consumed_dev, uint8_t* sat, int first_phase, int last_phase) {
     const int ntiles = tiles_x * tiles_y;
     const uint32_t* order = nullptr;
-    if (c->opt_tile_lpt && c->r_P > 0 && ntiles > 256) {
+    if (c->opt_tile_lpt && !c->r_bin32 && c->r_P > 0 && ntiles > 256) {  // (tile_order_key_kernel reads per-tile ranges)
         GSX_HIP(c, c->r_tile_order.ensure(sizeof(uint32_t) * 4 * (size_t)ntiles));
         uint32_t* k0 = c->r_tile_order.as<uint32_t>();
         uint32_t *v0 = k0 + ntiles, *k1 = v0 + ntiles, *v1 = k1 + ntiles;
@@ -405,9 +466,17 @@ int launch_blend(Ctx* c, const uint32_t* vals, int W, int H, int tiles_x, int ti
     }
     ProfScope ps(c, "render_blend");
     if (c->opt_blend_pk2 == 2) {
-        hipLaunchKernelGGL(blend4_kernel, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
-                           c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
-                           c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase);
+        const int bins_x = (tiles_x + 1) / 2, bins_y = (tiles_y + 1) / 2;
+        if (c->r_bin32)
+            hipLaunchKernelGGL(blend4_kernel<true>, dim3(4 * bins_x * bins_y), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(),
+                               (const uint32_t*)nullptr, vals, c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
+                               c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase,
+                               bins_x, tiles_y);
+        else
+            hipLaunchKernelGGL(blend4_kernel<false>, dim3(ntiles), dim3(kBlend4Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
+                               c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,
+                               c->r_pre.as<int>(), (long long)c->rn, consumed_dev, c->r_image.as<float4>(), sat, first_phase, last_phase,
+                               bins_x, tiles_y);
     } else if (c->opt_blend_pk2) {
         hipLaunchKernelGGL(blend2_kernel, dim3(ntiles), dim3(kBlend2Threads), 0, c->stream, c->r_ranges.as<int2>(), order, vals,
                            c->r_rec.as<float4>(), W, H, tiles_x, dropped_dev,

@@ -278,6 +278,9 @@ struct Ctx {
     DevBuf r_sat;                        // u8 per tile: every pixel is opaque (1 - alpha < 1e-5): later depth phases skip it
     int opt_render_phases = 2;           // depth phases per frame (1 = bin and sort every pair at once)
     int opt_render_phase_ratio = 4;      // phase p ends at n / ratio^(K-1-p) splats (front to back)
+    int opt_render_bin32 = 1;            // bin, sort and range the splats by 32x32-pixel BINS (2x2 tiles); a pair carries the mask of the bin's tiles
+                                         // the splat's rectangle covers (one-wave blend kernel, no exact_cull, < 2^28 splats; else 16x16)
+    int r_bin32 = 0;                     // the frame being rendered uses bins (set by render_view, read by launch_blend)
     unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
     static constexpr int kMaxFrames = 6;
     Ctx* twins[kMaxFrames - 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // gsx_render_views: further streams + per-frame buffers, aliasing this context's scene

@@ -665,7 +665,14 @@ __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restri
 // No lane ever loops over a rectangle on its own: a splat covering 4000 tiles costs the wave 63 rounds, not one lane
 // 4000, which is what made the exact test a net loss when every thread walked its own rectangle.
 // COUNT and EMIT run the same tests on the same data (sat is not written in between), so the slots are exact.
-template <bool EMIT>
+//
+// BIN32 (option render_bin32): the candidates are 32x32-pixel BINS (2x2 tiles) instead of tiles.  A pair's key is the bin,
+// its value carries in bits 28-31 the mask of the bin's tiles (bit = 2 * (ty & 1) + (tx & 1)) that the splat's rectangle
+// covers and that are not opaque yet; the blend kernel of a tile walks its bin's list and takes the entries whose mask names
+// it - in list order, so a tile blends exactly the splats, in exactly the order, of the per-tile lists.  A splat's rectangle
+// spans about half as many bins as tiles: half the pairs to emit, sort and range.  `tiles_x` is then the bins per row and
+// `sat` holds four bytes per bin (bin * 4 + bit), read as one word.
+template <bool EMIT, bool BIN32>
 __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, const uint32_t* __restrict__ by_depth,
                                                    const uint32_t* __restrict__ tile_rect, const float4* __restrict__ rec,
                                                    float H, int tiles_x, int exact,
@@ -680,8 +687,9 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
     const uint32_t i = live ? by_depth[j] : 0u;
     const uint32_t rect = live ? tile_rect[i] : kEmptyRect;
     const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
-    const uint32_t w = tx1 >= tx0 ? tx1 - tx0 + 1u : 0u;
-    const uint32_t area = w * (ty1 >= ty0 ? ty1 - ty0 + 1u : 0u);
+    constexpr uint32_t kSh = BIN32 ? 1u : 0u;  // candidate = bin: the rectangle in bin units
+    const uint32_t w = tx1 >= tx0 ? (tx1 >> kSh) - (tx0 >> kSh) + 1u : 0u;
+    const uint32_t area = w * (ty1 >= ty0 ? (ty1 >> kSh) - (ty0 >> kSh) + 1u : 0u);
     // candidate offsets inside the wave: exclusive scan of the areas
     uint32_t inc = area;
 #pragma unroll
@@ -724,25 +732,38 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
         const uint32_t s_start = __shfl(cstart, lo);
         const uint32_t s_rect = __shfl(rect, lo);
         const uint32_t s_tx0 = s_rect & 255u, s_tx1 = (s_rect >> 8) & 255u, s_ty0 = (s_rect >> 16) & 255u;
-        const uint32_t s_w = s_tx1 - s_tx0 + 1u;
+        const uint32_t s_w = (s_tx1 >> kSh) - (s_tx0 >> kSh) + 1u;
         const uint32_t local = target - s_start;
         const uint32_t ry = local / s_w, rx = local - ry * s_w;
-        const uint32_t tx = s_tx0 + rx, ty = s_ty0 + ry;
+        const uint32_t tx = (s_tx0 >> kSh) + rx, ty = (s_ty0 >> kSh) + ry;
         const uint32_t tile = ty * (uint32_t)tiles_x + tx;
         bool keep = valid;
+        uint32_t tag = 0u;  // BIN32: the mask of the bin's tiles, in the value's top four bits
+        if (BIN32) {
+            const uint32_t s_ty1 = s_rect >> 24;
+            const uint32_t cx = 2u * tx, cy = 2u * ty;
+            const uint32_t xb = (cx >= s_tx0 && cx <= s_tx1 ? 1u : 0u) | (cx + 1u >= s_tx0 && cx + 1u <= s_tx1 ? 2u : 0u);
+            uint32_t m = (cy >= s_ty0 && cy <= s_ty1 ? xb : 0u) | (cy + 1u >= s_ty0 && cy + 1u <= s_ty1 ? xb << 2 : 0u);
+            if (sat && keep) {
+                const uint32_t sw = reinterpret_cast<const uint32_t*>(sat)[tile];
+                m &= ~((sw & 0xffu ? 1u : 0u) | (sw & 0xff00u ? 2u : 0u) | (sw & 0xff0000u ? 4u : 0u) | (sw & 0xff000000u ? 8u : 0u));
+            }
+            keep = keep && m != 0u;
+            tag = m << 28;
+        }
         if (exact) {  // wave-uniform
             const int s_test = __shfl((int)test, lo);
             const float a0 = __shfl(r0.x, lo), a1 = __shfl(r0.y, lo), a2 = __shfl(r0.z, lo), a3 = __shfl(r0.w, lo);
             const float b0 = __shfl(r1.x, lo), b1 = __shfl(r1.y, lo);
             if (keep && s_test) keep = tile_touches(a0, a1, a2, a3, b0, b1, H, tx, ty);
         }
-        if (sat && keep) keep = sat[tile] == 0;
+        if (!BIN32 && sat && keep) keep = sat[tile] == 0;
         if (EMIT && !exact && !sat) {  // wave-uniform fast path: slot = the splat's offset + the candidate's rank in its rectangle
             const uint32_t pos = __shfl(my_off, lo) + local;  // shuffles outside the predicate: every lane must take part
             const uint32_t s_i = __shfl(i, lo);
             if (keep) {
                 keys[pos] = tile;
-                vals[pos] = s_i;
+                vals[pos] = s_i | tag;
             }
             continue;
         }
@@ -764,7 +785,7 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
             const uint32_t rank = s_prior + (uint32_t)__popcll(verdict & upto & ~from);
             if (keep) {
                 keys[s_off + rank] = tile;
-                vals[s_off + rank] = s_i;
+                vals[s_off + rank] = s_i | tag;
             }
         }
         kept_run += mine;
@@ -964,15 +985,24 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     if (tiles_x > 256 || tiles_y > 256)
         return fail(c, GSX_E_UNSUPPORTED, "render_view: %dx%d exceeds 4096 pixels per side", W, H);
-    const long long n = c->rn;
     const size_t img_bytes = sizeof(float) * 4 * (size_t)W * H;
     GSX_HIP(c, c->r_image.ensure(img_bytes));
     c->r_W = W;
     c->r_H = H;
     const int ntiles = tiles_x * tiles_y;
     constexpr int kMaxPhases = 8;
-    GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)ntiles));
-    GSX_HIP(c, c->r_sat.ensure((size_t)ntiles));
+    const long long n = c->rn;
+    // 32x32-pixel bins (see bin_kernel): the one-wave blend kernel reads the masks; a value's top four bits are the mask
+    const bool bin32 = c->opt_render_bin32 && c->opt_blend_pk2 == 2 && !c->opt_exact_cull && n < (1ll << 28);
+    c->r_bin32 = bin32;
+    const int bins_x = (tiles_x + 1) / 2, bins_y = (tiles_y + 1) / 2;
+    const int nlists = bin32 ? bins_x * bins_y : ntiles;          // lists the pairs are sorted into
+    const int lists_x = bin32 ? bins_x : tiles_x;
+    const auto count_k = bin32 ? bin_kernel<false, true> : bin_kernel<false, false>;
+    const auto emit_k = bin32 ? bin_kernel<true, true> : bin_kernel<true, false>;
+    const size_t sat_bytes = bin32 ? 4 * (size_t)nlists : (size_t)ntiles;
+    GSX_HIP(c, c->r_ranges.ensure(sizeof(int2) * (size_t)nlists));
+    GSX_HIP(c, c->r_sat.ensure(sat_bytes));
     constexpr size_t kSmallBytes = 256 + (size_t)kConsumedSlots * 128;
     GSX_HIP(c, c->r_small.ensure(kSmallBytes));
     // [2]=dropped, then u64: [3 + p]=pairs of phase p; from byte 256: pairs consumed, kConsumedSlots
@@ -1020,7 +1050,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     }
     bounds[K] = n;
     int tile_bits = 1;
-    while ((1 << tile_bits) < ntiles) ++tile_bits;
+    while ((1 << tile_bits) < nlists) ++tile_bits;
     if (c->r_pair_cap == 0) c->r_pair_cap = std::max<size_t>((size_t)1 << 20, 2 * (size_t)n);
 
     for (int attempt = 0;; ++attempt) {
@@ -1029,7 +1059,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
         GSX_HIP(c, c->r_keys1.ensure(4 * cap));
         GSX_HIP(c, c->r_vals0.ensure(4 * cap));
         GSX_HIP(c, c->r_vals1.ensure(4 * cap));
-        GSX_HIP(c, hipMemsetAsync(c->r_sat.p, 0, (size_t)ntiles, c->stream));
+        GSX_HIP(c, hipMemsetAsync(c->r_sat.p, 0, sat_bytes, c->stream));
         GSX_HIP(c, hipMemsetAsync(small, 0, kSmallBytes, c->stream));  // counters
         if (!ext_pre) {  // (a frame that is redone because a phase overflowed the pair buffers keeps the pre pass's records)
             GSX_HIP(c, hipMemcpyAsync(c->r_pre.p, kPreInit, sizeof kPreInit, hipMemcpyHostToDevice, c->stream));
@@ -1062,8 +1092,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             if (m > 0) {
                 {
                     ProfScope ps(c, "render_bin_count");
-                    hipLaunchKernelGGL(bin_kernel<false>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
-                                       c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, tiles_x,
+                    hipLaunchKernelGGL(count_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
+                                       j0, j1, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, c->r_count.as<uint32_t>(), (const uint32_t*)nullptr,
                                        (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
                 }
@@ -1072,8 +1102,8 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                 if (rc) return rc;
                 {
                     ProfScope ps(c, "render_bin_emit");
-                    hipLaunchKernelGGL(bin_kernel<true>, dim3(grid_for(m)), dim3(kRB), 0, c->stream, j0, j1, by_depth,
-                                       c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, tiles_x,
+                    hipLaunchKernelGGL(emit_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
+                                       j0, j1, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, (uint32_t*)nullptr, c->r_offset.as<uint32_t>(),
                                        c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap);
                 }
@@ -1082,12 +1112,12 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                                           c->r_vals1.as<uint32_t>(), (long long)cap, pairs_dev + p, tile_bits, &where);
                 if (rc) return rc;
             }
-            GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)ntiles, c->stream));
+            GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)nlists, c->stream));
             if (m > 0) {
                 ProfScope ps(c, "render_ranges");
                 hipLaunchKernelGGL(ranges_kernel, dim3(grid_for((long long)cap)), dim3(kRB), 0, c->stream,
                                    where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap,
-                                   ntiles, c->r_ranges.as<int2>());
+                                   nlists, c->r_ranges.as<int2>());
                 GSX_HIP(c, hipGetLastError());
             }
             c->r_sorted_in = where;
@@ -1163,6 +1193,7 @@ static int twin_sync_scene(Ctx* c, int k) {
     t->opt_render_phases = c->opt_render_phases;
     t->opt_render_phase_ratio = c->opt_render_phase_ratio;
     t->opt_exact_cull = c->opt_exact_cull;
+    t->opt_render_bin32 = c->opt_render_bin32;
     t->opt_blend_pk2 = c->opt_blend_pk2;
     t->opt_tile_lpt = c->opt_tile_lpt;
     if (t->r_pair_cap < c->r_pair_cap) t->r_pair_cap = c->r_pair_cap;

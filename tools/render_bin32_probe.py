@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""GPU box: 32x32-pixel sort bins (option render_bin32) against per-tile lists, interleaved on one context: views/s of
+gsx_render_views with four frames in flight, (list, splat) pairs sorted and records evaluated per view, and whether the frames
+are bit-identical (they must be: a tile takes the entries of its bin's list whose mask names it, in list order).
+argv: [c1] configs[1] sizes; [4k] 3840x2160; [small] a few odd sizes first (frame edges: half-empty bins)."""
+import importlib, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("3d_gaussian_splatting_project_amd")
+scene = pkg.scene
+args = sys.argv[1:]
+n, W, H = (500_000, 1280, 720) if "c1" in args else (3_000_000, 1920, 1080)
+if "4k" in args:
+    W, H = 3840, 2160
+seed = scene.BASE_SEED + 3
+ok = True
+if "small" in args:
+    for (m, w, h, deg, phases) in ((20_000, 333, 177, 0, 2), (50_000, 640, 360, 2, 3), (5_000, 31, 17, 1, 1), (80_000, 1000, 40, 3, 2)):
+        xyz = scene.make_positions(m, seed + m)
+        a = scene.make_splat_attributes(m, seed + m, sh_degree=deg)
+        cams = scene.make_cameras(6, w, h, convention="c2w")
+        with pkg.Context(0) as c:
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            if deg:
+                c.upload_sh(a["f_rest"], deg)
+            c.set_option("render_phases", phases)
+            out = {}
+            for b in (0, 1):
+                c.set_option("render_bin32", b)
+                out[b] = (c.render_views(cams, w, h), [c.render_view(cam, w, h) for cam in cams[:2]])
+            same = all(np.array_equal(x, y) for x, y in zip(out[0][0], out[1][0])) and all(np.array_equal(x, y) for x, y in zip(out[0][1], out[1][1]))
+            ok &= same
+            print(f"{m} splats {w}x{h} SH {deg} phases {phases}: frames identical {same}  max alpha {max(float(f[..., 3].max()) for f in out[1][0]):.3f}", flush=True)
+xyz = scene.make_positions(n, seed)
+a = scene.make_splat_attributes(n, seed, sh_degree=3)
+cams = scene.make_cameras(24, W, H, convention="c2w")
+with pkg.Context(0) as c:
+    c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+    c.upload_sh(a["f_rest"], 3)
+    ref = None
+    for b in (0, 1, 0, 1, 0, 1):
+        c.set_option("render_bin32", b)
+        c.render_views(cams, W, H, to_host=False)
+        t0 = time.perf_counter()
+        for rep in range(3):
+            c.render_views(cams, W, H, to_host=False)
+        dt = (time.perf_counter() - t0) / (3 * len(cams))
+        st = (c.render_num_pairs() // (3 * 0 + len(cams)), c.render_num_pairs_consumed() // len(cams))  # of the last call: (pairs sorted, records evaluated) per view
+        frames = c.render_views(cams[:6], W, H)
+        if ref is None:
+            ref = frames
+        same = all(np.array_equal(x, y) for x, y in zip(ref, frames))
+        ok &= same
+        print(f"render_bin32={b}: {dt * 1e3:.3f} ms/view = {1 / dt:.0f} views/s   stats {st}   frames identical to per-tile lists: {same}", flush=True)
+sys.exit(0 if ok else 1)
