@@ -90,7 +90,8 @@ def test_frames_match_the_reference_shaders_run_on_llvmpipe(ctx, gsx):
         check_against_gl_frame(img, c[9], c[0] + " (render_views)")
     # every blend kernel, bounding-box and exact binning, one to three depth phases: the same frames
     for opts in ({"blend_pk2": 0}, {"blend_pk2": 1, "exact_cull": 1}, {"blend_pk2": 2, "exact_cull": 1, "render_phases": 3},
-                 {"blend_pk2": 1, "render_phases": 1}, {"blend_pk2": 2, "tile_lpt": 1, "render_phase_ratio": 2}):
+                 {"blend_pk2": 1, "render_phases": 1}, {"blend_pk2": 2, "tile_lpt": 1, "render_phase_ratio": 2},
+                 {"blend_pk2": 2, "render_bin32": 0}, {"blend_pk2": 2, "render_bin32": 0, "render_phases": 3}):
         with gsx.Context(0) as c2:
             for k, v in opts.items():
                 c2.set_option(k, v)
@@ -221,11 +222,13 @@ def test_render_views_two_frames_in_flight(gsx):
         assert c.render_views([], W, H, to_host=False) is None
 
 
-def test_pair_count_beyond_31_bits_is_an_error_not_a_wrapped_offset(gsx):
-    """the (tile, splat) pair count of a close-up of a very large scene can pass 2^31 (offsets are 32 bit).
-    300 k splats that each cover the whole 1080p frame = 2.4e9 pairs in a single depth phase: the 64-bit grand total of
-    the scan must turn that into GSX_E_RANGE (ValueError) - never into wrapped offsets and out-of-bounds writes."""
-    n, W, H = 300_000, 1920, 1080
+@pytest.mark.parametrize("n,bin32", [(300_000, 0), (1_100_000, 1)])
+def test_pair_count_beyond_31_bits_is_an_error_not_a_wrapped_offset(gsx, n, bin32):
+    """the (list, splat) pair count of a close-up of a very large scene can pass 2^31 (offsets are 32 bit).
+    300 k splats that each cover the whole 1080p frame = 2.4e9 pairs in a single depth phase with per-tile lists (8160 tiles),
+    1.1 M such splats = 2.2e9 with the 32x32-pixel bins (2040 bins): the 64-bit grand total of the scan must turn that into
+    GSX_E_RANGE (ValueError) - never into wrapped offsets and out-of-bounds writes."""
+    W, H = 1920, 1080
     rng = np.random.default_rng(3)
     xyz = (rng.normal(size=(n, 3)) * 0.05).astype(np.float32)
     scale = np.full((n, 3), np.log(50.0), np.float32)           # far wider than the frame: the axes are capped at 1024 px
@@ -233,12 +236,55 @@ def test_pair_count_beyond_31_bits_is_an_error_not_a_wrapped_offset(gsx):
     cam = scene.make_cameras(3, W, H, convention="c2w")[0]
     with gsx.Context(0) as c:
         c.set_option("render_phases", 1)
+        c.set_option("render_bin32", bin32)
         c.upload_splats(xyz, scale, rot, np.zeros(n, np.float32), np.zeros((n, 3), np.float32))
         with pytest.raises(ValueError, match="render_phases"):
             c.render_view(cam, W, H, to_host=False)
         # the context stays usable
         c.upload_splats(xyz[:1000], scale[:1000] - np.float32(np.log(500.0)), rot[:1000], np.zeros(1000, np.float32), np.zeros((1000, 3), np.float32))
         assert np.isfinite(c.render_view(cam, W, H)).all()
+
+
+def test_bins_of_2x2_tiles_give_the_frames_of_per_tile_lists(gsx):
+    """Option render_bin32 (default on): the (list, splat) pairs are binned, sorted and ranged by 32x32-pixel bins and carry
+    the mask of the bin's tiles the splat's rectangle covers; a tile walks its bin's list and takes the entries that name it,
+    in list order, staged in the same chunks of 64 as its own list would be.  So: bit for bit the frames of per-tile lists
+    (render_bin32 = 0), the same number of records evaluated, fewer pairs sorted - for frames whose last column / row of bins
+    is half empty or a single tile, one to three depth phases (tiles of one bin turn opaque in different phases), saturating
+    lists longer than the 256-entry fetch, with and without the SH colour path, one frame at a time and several in flight;
+    and the oracle's frame within 1e-4."""
+    cases = ((20_000, 333, 177, 0, 2, 1.0, 0.0), (60_000, 640, 360, 2, 3, 2.5, 2.0), (5_000, 31, 17, 1, 1, 3.0, 0.0), (40_000, 1000, 40, 3, 2, 1.5, 1.0),
+             (3_000, 640, 360, 0, 2, 12.0, 0.0), (150_000, 1920, 1080, 0, 2, 2.0, 1.0))
+    for n, W, H, deg, phases, grow, opaq in cases:
+        seed = scene.BASE_SEED + n + W
+        xyz = scene.make_positions(n, seed) * np.float32(0.7)
+        a = scene.make_splat_attributes(n, seed, sh_degree=max(deg, 1))
+        a["scale"] += np.float32(np.log(grow))
+        a["opacity"] += np.float32(opaq)
+        cams = scene.make_cameras(6, W, H, convention="c2w")
+        out = {}
+        with gsx.Context(0) as c:
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            if deg:
+                c.upload_sh(a["f_rest"][:, :3 * ((deg + 1) ** 2 - 1)], deg)
+            c.set_option("render_phases", phases)
+            for b in (0, 1):
+                c.set_option("render_bin32", b)
+                many = c.render_views(cams, W, H)
+                stats = (c.render_num_pairs(), c.render_num_pairs_consumed())
+                single = [c.render_view(cam, W, H) for cam in cams[:2]]
+                out[b] = (many, stats, single)
+        for k in range(len(cams)):
+            assert np.array_equal(out[0][0][k], out[1][0][k]), (n, W, H, k)
+        for k in range(2):
+            assert np.array_equal(out[0][2][k], out[1][2][k]) and np.array_equal(out[0][2][k], out[0][0][k]), (n, W, H, k)
+        assert out[0][1][1] == out[1][1][1], "records evaluated"
+        assert out[1][1][0] <= out[0][1][0], "pairs sorted"
+        if W >= 640 and H >= 360:
+            assert out[1][1][0] < 0.8 * out[0][1][0], (n, W, H, out[0][1], out[1][1])
+        if deg == 0 and n <= 60_000:
+            want = oracle.render_scene(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cams[1], W, H)
+            assert np.abs(out[1][0][1] - want).max() <= TOL
 
 
 def test_export_splat_file(ctx, g, tmp_path):

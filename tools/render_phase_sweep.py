@@ -34,12 +34,25 @@ with pkg.Context(0) as c:
             cnt, ms = c.profile_get("render_blend")
             c.profile(False)
             print(f"blend_pk2={mode}: render_blend {ms / 8:.4f} ms per view ({cnt} launches)", flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "bin32":   # depth phases again, now that a pair costs less (32x32-pixel bins); per-kernel times first
+        sweep = ({}, {"render_phases": 1}, {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 2, "render_phase_ratio": 8},
+                 {"render_phases": 2, "render_phase_ratio": 2}, {"render_phases": 3}, {"render_bin32": 0}) * 2 + ({},)
+        for b in (0, 1):
+            c.set_option("render_bin32", b)
+            c.render_view(cams[0], W, H, to_host=False)
+            c.profile(True)
+            for cam in cams[:8]:
+                c.render_view(cam, W, H, to_host=False)
+            names = ("render_pre", "render_bucket", "radix_hist", "radix_rowscan", "radix_scatter", "render_bin_count", "scan", "render_bin_emit", "render_ranges", "render_blend")
+            ms = {k: c.profile_get(k)[1] / 8 for k in names}
+            c.profile(False)
+            print(f"render_bin32={b}: kernel ms per view " + " ".join(f"{k}={v:.4f}" for k, v in ms.items()) + f"  sum {sum(ms.values()):.4f}", flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == "cull":    # bounding-box binning against the exact ellipse test, interleaved
         sweep = ({}, {"exact_cull": 1}) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2})
     for opts in sweep:
-        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2}
+        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2, "render_bin32": 1}
         base.update(opts)
         for k, v in base.items():
             c.set_option(k, v)
