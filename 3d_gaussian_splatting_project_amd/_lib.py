@@ -128,6 +128,7 @@ _SIGS = {
     "gsx_debug_filter_check": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gsx_debug_cull_planes": (C.c_int, [C.POINTER(Camera), C.c_void_p]),
     "gsx_debug_sort_pairs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "gsx_debug_sort_pairs_drop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_int64)]),
     "gsx_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "gsx_profile_reset": (C.c_int, [C.c_void_p]),
     "gsx_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

@@ -182,6 +182,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     }
     else if (k == "render_multi_pre") c->opt_render_multi_pre = value != 0;
     else if (k == "render_bin32") c->opt_render_bin32 = value != 0;
+    else if (k == "render_compact") c->opt_render_compact = value != 0;
     else if (k == "render_share_stream") {
         if ((value != 0) != (c->opt_render_share_stream != 0)) gsx::render_release_twin(c);  // the extra frames' streams are made anew
         c->opt_render_share_stream = value != 0;
@@ -605,6 +606,36 @@ int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t
     GSX_HIP(c, hipMemcpyAsync(keys, where ? k1.p : k0.p, nb, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipMemcpyAsync(values, where ? v1.p : v0.p, nb, hipMemcpyDeviceToHost, c->stream));
     GSX_HIP(c, hipStreamSynchronize(c->stream));
+    return GSX_OK;
+}
+
+int gsx_debug_sort_pairs_drop(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits, int64_t* kept_out) {
+    CTX_OR_FAIL(ctx);
+    if (n < 1 || bits < 1 || bits > 32 || !keys || !values || !kept_out)
+        return gsx::fail(c, GSX_E_INVALID, "debug_sort_pairs_drop: bad arguments");
+    GSX_HIP(c, hipSetDevice(c->device));
+    gsx::DevBuf k0, v0, k1, v1, cnt;
+    const size_t nb = sizeof(uint32_t) * (size_t)n;
+    GSX_HIP(c, k0.ensure(nb));
+    GSX_HIP(c, v0.ensure(nb));
+    GSX_HIP(c, k1.ensure(nb));
+    GSX_HIP(c, v1.ensure(nb));
+    GSX_HIP(c, cnt.ensure(8));
+    GSX_HIP(c, hipMemcpyAsync(k0.p, keys, nb, hipMemcpyHostToDevice, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(v0.p, values, nb, hipMemcpyHostToDevice, c->stream));
+    // (the result's slots behind the kept elements are not written: let them read as 0xff bytes, never as stale memory)
+    GSX_HIP(c, hipMemsetAsync(k1.p, 0xff, nb, c->stream));
+    GSX_HIP(c, hipMemsetAsync(v1.p, 0xff, nb, c->stream));
+    int where = 0;
+    int rc = gsx::radix_sort_pairs_drop(c, k0.as<uint32_t>(), v0.as<uint32_t>(), k1.as<uint32_t>(), v1.as<uint32_t>(), n, nullptr,
+                                        bits, &where, cnt.as<unsigned long long>());
+    if (rc) return rc;
+    unsigned long long kept = 0;
+    GSX_HIP(c, hipMemcpyAsync(&kept, cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(keys, where ? k1.p : k0.p, nb, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipMemcpyAsync(values, where ? v1.p : v0.p, nb, hipMemcpyDeviceToHost, c->stream));
+    GSX_HIP(c, hipStreamSynchronize(c->stream));
+    *kept_out = (int64_t)kept;
     return GSX_OK;
 }
 

@@ -277,9 +277,10 @@ struct Ctx {
     int r_sorted_in = 0;
     DevBuf r_sat;                        // u8 per tile: every pixel is opaque (1 - alpha < 1e-5): later depth phases skip it
     int opt_render_phases = 2;           // depth phases per frame (1 = bin and sort every pair at once)
-    int opt_render_phase_ratio = 4;      // phase p ends at n / ratio^(K-1-p) splats (front to back)
+    int opt_render_phase_ratio = 6;      // phase p ends at nvis / ratio^(K-1-p) splats (front to back; nvis = the splats with a rectangle in the view; 4 until the level-1 sort left the others out)
     int opt_render_bin32 = 1;            // bin, sort and range the splats by 32x32-pixel BINS (2x2 tiles); a pair carries the mask of the bin's tiles
                                          // the splat's rectangle covers (one-wave blend kernel, no exact_cull, < 2^28 splats; else 16x16)
+    int opt_render_compact = 1;          // the level-1 sort leaves out the splats without a rectangle in the view (its first pass is the partition)
     int r_bin32 = 0;                     // the frame being rendered uses bins (set by render_view, read by launch_blend)
     unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
     static constexpr int kMaxFrames = 6;
@@ -345,6 +346,8 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
                      int* result_in);
 int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
                          const unsigned long long* n_dev, int bits, int* result_in);
+int radix_sort_pairs_drop(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
+                          const unsigned long long* n_dev, int bits, int* result_in, unsigned long long* n_kept);  // elements with key 0xffffffff are left out
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
 int second_stream(Ctx* c);

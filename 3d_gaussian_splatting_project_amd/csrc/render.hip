@@ -444,9 +444,11 @@ __global__ __launch_bounds__(kRB) void pre_kernel(const uint4* __restrict__ tex,
         depth[i] = o.depth;
         lo = min(lo, o.depth);
         hi = max(hi, o.depth);
-        rec[3 * i] = o.r0;
-        rec[3 * i + 1] = o.r1;
-        rec[3 * i + 2] = make_float4(o.r2.x, o.r2.y, 0.f, 0.f);
+        if (o.rect != kEmptyRect || i == 0) {  // a record is read only through a list the splat was binned into - and splat 0's by the epilogue
+            rec[3 * i] = o.r0;
+            rec[3 * i + 1] = o.r1;
+            rec[3 * i + 2] = make_float4(o.r2.x, o.r2.y, 0.f, 0.f);
+        }
         tile_rect[i] = o.rect;
         if (i == 0) pre[2] = (int)o.rect;
     }
@@ -504,7 +506,9 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
             __builtin_nontemporal_store(g.depth, &a.depth[v][i]);  // streaming stores: the records are not read again here
             lo[v] = min(lo[v], g.depth);
             hi[v] = max(hi[v], g.depth);
-            a.rec[v][3 * i] = g.r0;  // (ordinary stores: the three 16-byte pieces of a record meet in the L2 before they leave it)
+            // (ordinary stores: the three 16-byte pieces of a record meet in the L2 before they leave it; a splat without a
+            // rectangle - two in five on the bench scene - is in no list and writes none: only splat 0's is read regardless, by the epilogue)
+            if (g.rect != kEmptyRect || i == 0) a.rec[v][3 * i] = g.r0;
             __builtin_nontemporal_store(g.rect, &a.rect[v][i]);
             if (i == 0) a.pre[v][2] = (int)g.rect;
             g1x[v] = g.g1x, g1y[v] = g.g1y, fade[v] = g.fade;
@@ -550,8 +554,10 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
                 r1 = make_float4(g1x[v], g1y[v], col[0], col[1]);
                 r2 = make_float2(col[2], col[3]);
             }
-            a.rec[v][3 * i + 1] = r1;
-            a.rec[v][3 * i + 2] = make_float4(r2.x, r2.y, 0.f, 0.f);
+            if (((want >> v) & 1u) || i == 0) {  // (want <=> the view gave the splat a rectangle)
+                a.rec[v][3 * i + 1] = r1;
+                a.rec[v][3 * i + 2] = make_float4(r2.x, r2.y, 0.f, 0.f);
+            }
         }
     }
 #pragma unroll
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(kRB) void pre_multi_kernel(const uint4* __restrict_
 __global__ __launch_bounds__(kRB) void bucket_kernel(const int* __restrict__ depth, long long n, const int* __restrict__ minmax,
                                                       uint32_t* __restrict__ bucket, uint32_t* __restrict__ key,
                                                       uint32_t* __restrict__ idx, uint32_t* __restrict__ tile_rect,
-                                                      int* __restrict__ dropped) {
+                                                      int* __restrict__ dropped, int compact) {
     const long long i = (long long)blockIdx.x * kRB + threadIdx.x;
     bool drop = false;
     if (i < n) {
@@ -574,7 +580,11 @@ __global__ __launch_bounds__(kRB) void bucket_kernel(const int* __restrict__ dep
         const bool in_range = b >= 0 && b < 65536;
         const uint32_t v = in_range ? (uint32_t)b : 65536u;
         bucket[i] = v;
-        key[i] = in_range ? v : 65535u;  // 16-bit sort key: a dropped splat covers no tile, where it sorts does not matter
+        // 16-bit sort key: a dropped splat covers no tile, where it sorts does not matter.  compact: a splat that covers no tile
+        // (dropped, or without a rectangle in this view: behind the camera, off the frame, between the pixel centres) gets the
+        // key the level-1 sort leaves out (radix_sort_pairs_drop) - the bin kernels then see the others only, in their order
+        const bool seen = in_range && tile_rect[i] != kEmptyRect;
+        key[i] = compact ? (seen ? v : 0xffffffffu) : (in_range ? v : 65535u);
         idx[i] = (uint32_t)i;
         drop = !in_range;
         if (drop) tile_rect[i] = kEmptyRect;
@@ -673,7 +683,8 @@ __global__ __launch_bounds__(kRB) void scan_down_kernel(const uint32_t* __restri
 // spans about half as many bins as tiles: half the pairs to emit, sort and range.  `tiles_x` is then the bins per row and
 // `sat` holds four bytes per bin (bin * 4 + bit), read as one word.
 template <bool EMIT, bool BIN32>
-__global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, const uint32_t* __restrict__ by_depth,
+__global__ __launch_bounds__(kRB) void bin_kernel(const unsigned long long* __restrict__ nvis_dev, long long div0, long long div1,
+                                                   long long m_cap, const uint32_t* __restrict__ by_depth,
                                                    const uint32_t* __restrict__ tile_rect, const float4* __restrict__ rec,
                                                    float H, int tiles_x, int exact,
                                                    const uint8_t* __restrict__ sat, uint32_t* __restrict__ count_out,
@@ -681,9 +692,15 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
                                                    uint32_t* __restrict__ vals, const unsigned long long* __restrict__ total_dev,
                                                    unsigned long long cap) {
     if (EMIT && *total_dev > cap) return;  // the phase does not fit the pair buffers: the host redoes the frame with larger ones
-    const long long j = j0 + (long long)blockIdx.x * kRB + threadIdx.x;
+    // the phase's splats: [nvis / div0, nvis / div1) of the depth order, nvis = the splats the level-1 sort kept (on the device:
+    // the host never waits for it; the launch covers m_cap >= the phase's length, and COUNT writes every slot of it)
+    const long long nvis = (long long)*nvis_dev;
+    const long long j0 = div0 ? nvis / div0 : 0, j1 = nvis / div1;
+    const long long rel = (long long)blockIdx.x * kRB + threadIdx.x;
+    const long long j = j0 + rel;
     const int lane = threadIdx.x & 63;
     const bool live = j < j1;
+    const bool slot = rel < m_cap;
     const uint32_t i = live ? by_depth[j] : 0u;
     const uint32_t rect = live ? tile_rect[i] : kEmptyRect;
     const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
@@ -699,12 +716,12 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
     }
     const uint32_t total = __shfl(inc, 63);
     if (total == 0) {  // wave-uniform
-        if (!EMIT && live) count_out[j - j0] = 0u;
+        if (!EMIT && slot) count_out[rel] = 0u;
         return;
     }
     const uint32_t cstart = inc - area;
     if (!EMIT && !exact && !sat) {  // wave-uniform: nothing to test, every tile of the rectangle is kept
-        if (live) count_out[j - j0] = area;
+        if (slot) count_out[rel] = area;  // (a slot past the phase's end: area 0)
         return;
     }
     const bool test = exact && area > 1u;  // a one-tile rectangle holds the centre's tile or touches it by construction
@@ -713,7 +730,7 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
         r0 = rec[3 * (size_t)i];
         r1 = rec[3 * (size_t)i + 1];
     }
-    const uint32_t my_off = EMIT && live ? offset[j - j0] : 0u;
+    const uint32_t my_off = EMIT && live ? offset[rel] : 0u;
     uint32_t kept_run = 0;  // kept candidates of MY splat in the rounds so far
     // every lane runs every round: the shuffles read registers of ALL lanes; only the stores are predicated
     for (uint32_t base = 0; base < total; base += 64u) {
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(kRB) void bin_kernel(long long j0, long long j1, co
         }
         kept_run += mine;
     }
-    if (!EMIT && live) count_out[j - j0] = kept_run;
+    if (!EMIT && slot) count_out[rel] = kept_run;
 }
 
 __global__ __launch_bounds__(kRB) void ranges_kernel(const uint32_t* __restrict__ keys, const unsigned long long* __restrict__ total,
@@ -1011,6 +1028,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     unsigned long long* small64 = reinterpret_cast<unsigned long long*>(small);
     unsigned long long* consumed_dev = small64 + 32;
     unsigned long long* pairs_dev = small64 + 3;
+    unsigned long long* nvis_dev = small64 + 12;  // splats the level-1 sort kept (those with a rectangle in this view)
     c->r_P = 0;
     c->r_consumed = 0;
     if (n <= 0) {  // no splats at all: the cleared canvas
@@ -1038,17 +1056,17 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, c->r_d1.ensure(n4));
     GSX_HIP(c, c->r_d2.ensure(n4));
     GSX_HIP(c, c->r_d3.ensure(n4));
-    // depth phases: boundaries n / r^(K-1), n / r^(K-2), .., n / r, n
+    // depth phases: boundaries nvis / r^(K-1), nvis / r^(K-2), .., nvis / r, nvis of the depth order, nvis = the splats the
+    // level-1 sort keeps (on the device); the host sizes a phase's launches for n instead
     const int K = std::max(1, std::min(c->opt_render_phases, kMaxPhases));
     const long long ratio = std::max(2, std::min(c->opt_render_phase_ratio, 64));
-    long long bounds[kMaxPhases + 1];
-    bounds[0] = 0;
+    long long divs[kMaxPhases + 1];  // phase p = [nvis / divs[p], nvis / divs[p + 1]); divs[0] = 0 stands for the start
+    divs[0] = 0;
     for (int p = 1; p <= K; ++p) {
         long long div = 1;
-        for (int q = p; q < K; ++q) div *= ratio;
-        bounds[p] = std::max(bounds[p - 1], n / div);
+        for (int q = p; q < K; ++q) div = std::min<long long>(div * ratio, (long long)1 << 40);
+        divs[p] = div;
     }
-    bounds[K] = n;
     int tile_bits = 1;
     while ((1 << tile_bits) < nlists) ++tile_bits;
     if (c->r_pair_cap == 0) c->r_pair_cap = std::max<size_t>((size_t)1 << 20, 2 * (size_t)n);
@@ -1073,18 +1091,19 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
             ProfScope ps(c, "render_bucket");
             hipLaunchKernelGGL(bucket_kernel, dim3(grid_for(n)), dim3(kRB), 0, c->stream, c->r_depth.as<int>(), n, c->r_pre.as<int>(),
                                c->r_bucket.as<uint32_t>(), c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_rect.as<uint32_t>(),
-                               small + 2);
+                               small + 2, c->opt_render_compact);
         }
         GSX_HIP(c, hipGetLastError());
         // level 1: splats by depth bucket (stable)
         int dwhere = 0;
-        int rc = radix_sort_pairs(c, c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_d2.as<uint32_t>(), c->r_d3.as<uint32_t>(),
-                                  n, 16, &dwhere);
+        // (its first pass leaves out the splats bucket_kernel marked: nvis_dev = the ones that remain, sorted, in front)
+        int rc = radix_sort_pairs_drop(c, c->r_d0.as<uint32_t>(), c->r_d1.as<uint32_t>(), c->r_d2.as<uint32_t>(), c->r_d3.as<uint32_t>(),
+                                       n, nullptr, 16, &dwhere, nvis_dev);
         if (rc) return rc;
         const uint32_t* by_depth = dwhere ? c->r_d3.as<uint32_t>() : c->r_d1.as<uint32_t>();
         int first_phase = 1;
         for (int p = 0; p < K; ++p) {
-            const long long j0 = bounds[p], j1 = bounds[p + 1], m = j1 - j0;
+            const long long m = n / divs[p + 1];  // >= the phase's length nvis / divs[p + 1] - nvis / divs[p]
             const bool last = p == K - 1;
             if (m <= 0 && !last) continue;
             const uint8_t* sat = first_phase ? nullptr : c->r_sat.as<uint8_t>();
@@ -1093,7 +1112,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                 {
                     ProfScope ps(c, "render_bin_count");
                     hipLaunchKernelGGL(count_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
-                                       j0, j1, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
+                                       nvis_dev, divs[p], divs[p + 1], m, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, c->r_count.as<uint32_t>(), (const uint32_t*)nullptr,
                                        (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
                 }
@@ -1103,7 +1122,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                 {
                     ProfScope ps(c, "render_bin_emit");
                     hipLaunchKernelGGL(emit_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
-                                       j0, j1, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
+                                       nvis_dev, divs[p], divs[p + 1], m, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, (uint32_t*)nullptr, c->r_offset.as<uint32_t>(),
                                        c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap);
                 }
@@ -1194,6 +1213,7 @@ static int twin_sync_scene(Ctx* c, int k) {
     t->opt_render_phase_ratio = c->opt_render_phase_ratio;
     t->opt_exact_cull = c->opt_exact_cull;
     t->opt_render_bin32 = c->opt_render_bin32;
+    t->opt_render_compact = c->opt_render_compact;
     t->opt_blend_pk2 = c->opt_blend_pk2;
     t->opt_tile_lpt = c->opt_tile_lpt;
     if (t->r_pair_cap < c->r_pair_cap) t->r_pair_cap = c->r_pair_cap;

@@ -29,6 +29,7 @@ static constexpr int kSortWaves = kSortBlock / 64;
 static constexpr int kSortItems = 16;                          // keys per thread
 static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per workgroup (8192 measured 18 % slower)
 static constexpr int kWaveChunk = 64 * kSortItems;             // 1024 consecutive keys per wave
+static constexpr uint32_t kSortDropKey = 0xffffffffu;          // radix_sort_pairs_drop: an element with this key is left out
 
 // Element counts may live on the device (n_dev != nullptr: the rasterizer's pair count of the current depth phase, which
 // the host never waits for): the launch is then sized for the CAPACITY n, workgroups past the actual count leave at
@@ -39,6 +40,11 @@ __device__ __forceinline__ long long actual_count(long long n, const unsigned lo
     return v > (unsigned long long)n ? 0 : (long long)v;  // over capacity: the caller redoes the frame with larger buffers
 }
 
+// DROP (first pass of the rasterizer's level-1 sort): elements whose key is kSortDropKey take no part - they are not counted
+// and not scattered, and the pass's scatter kernel leaves the number of elements that remain in *n_out, which the later passes
+// read as their count.  A stable LSD pass IS an order-preserving partition: leaving the splats no tile will ever see out of
+// the sort costs nothing extra.
+template <bool DROP>
 __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, long long n,
                                                                  const unsigned long long* __restrict__ n_dev, int shift,
                                                                  uint32_t mask, uint32_t* __restrict__ hist, int ntiles) {
@@ -51,7 +57,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* 
 #pragma unroll 4
     for (int k = 0; k < kSortItems; ++k) {
         const long long i = base + (long long)k * kSortBlock + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & mask], 1u);
+        if (i < n) {
+            const uint32_t k = keys[i];
+            if (!DROP || k != kSortDropKey) atomicAdd(&h[(k >> shift) & mask], 1u);
+        }
     }
     __syncthreads();
     hist[(long long)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
@@ -89,13 +98,16 @@ __global__ __launch_bounds__(kSortBlock) void radix_rowscan_kernel(uint32_t* __r
     if (threadIdx.x == 0) rowsum[blockIdx.x] = carry_s;
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out, long long n,
                                                                     const unsigned long long* __restrict__ n_dev, int shift,
                                                                     uint32_t mask, const uint32_t* __restrict__ hist,
-                                                                    const uint32_t* __restrict__ rowsum, int ntiles) {
+                                                                    const uint32_t* __restrict__ rowsum, int ntiles,
+                                                                    unsigned long long* __restrict__ n_out) {
+    __shared__ uint32_t tile_kept;                // elements of this tile that take part (DROP: without the dropped ones)
     __shared__ uint32_t gbase[256];               // global start of this tile's run of each digit
     __shared__ uint32_t dstart[256];              // start of each digit inside the tile's locally sorted order
     __shared__ uint32_t wcount[kSortWaves][256];  // per-wave digit counters, then tile-local exclusive bases
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         uint32_t off = 0;
         for (int w = 0; w < wave; ++w) off += wsum[w];
         gbase[d] = off + inc - v + hist[(long long)d * ntiles + blockIdx.x];
+        if (DROP && blockIdx.x == 0 && d == kSortBlock - 1) *n_out = off + inc;  // all digits' totals: the elements that remain
     }
     __syncthreads();
 
@@ -135,9 +148,10 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const long long i = wbase_idx + r * 64 + lane;
-        const bool valid = i < n;
+        bool valid = i < n;
         key[r] = valid ? keys_in[i] : 0u;
         val[r] = valid ? vals_in[i] : 0u;
+        if (DROP) valid = valid && key[r] != kSortDropKey;
         const uint32_t dg = (key[r] >> shift) & mask;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -169,6 +183,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         for (int w = 0; w < wave; ++w) off += wsum[w];
         uint32_t run = off + inc - tot;
         dstart[d] = run;
+        if (d == kSortBlock - 1) tile_kept = off + inc;
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) {
             const uint32_t c = wcount[w][d];
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r) {
         const long long i = wbase_idx + r * 64 + lane;
-        if (i < n) {
+        if (i < n && (!DROP || key[r] != kSortDropKey)) {
             const uint32_t dg = (key[r] >> shift) & mask;
             const uint32_t lpos = wcount[wave][dg] + rank[r];
             sk[lpos] = key[r];
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         }
     }
     __syncthreads();
-    const int count = (int)min((long long)kSortTile, n - tile_base);
+    const int count = (int)tile_kept;  // (= min(kSortTile, n - tile_base) when nothing is dropped)
     for (int j = threadIdx.x; j < count; j += kSortBlock) {
         const uint32_t k = sk[j];
         const uint32_t dg = (k >> shift) & mask;
@@ -205,11 +220,19 @@ int radix_sort_pairs(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t*
     return radix_sort_pairs_dev(c, k0, v0, k1, v1, n, nullptr, bits, result_in);
 }
 
-// n: element count, or the buffers' capacity when the count is read from n_dev on the device (see actual_count).
 int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
                          const unsigned long long* n_dev, int bits, int* result_in) {
+    return radix_sort_pairs_drop(c, k0, v0, k1, v1, n, n_dev, bits, result_in, nullptr);
+}
+
+// n: element count, or the buffers' capacity when the count is read from n_dev on the device (see actual_count).
+// n_kept != nullptr: the elements whose key is kSortDropKey are left out by the first pass (see radix_hist_kernel) and
+// *n_kept (device) receives the number of the others, which end up sorted in the first *n_kept slots of the result.
+int radix_sort_pairs_drop(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
+                          const unsigned long long* n_dev, int bits, int* result_in, unsigned long long* n_kept) {
     *result_in = 0;
-    if ((n <= 1 && !n_dev) || n <= 0 || bits <= 0) return GSX_OK;
+    if (n_kept && (n_dev || n <= 0 || bits <= 0)) return fail(c, GSX_E_INVALID, "radix_sort_pairs_drop: needs a host count and at least one pass");
+    if ((n <= 1 && !n_dev && !n_kept) || n <= 0 || bits <= 0) return GSX_OK;
     const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
     GSX_HIP(c, c->sort_hist.ensure(sizeof(uint32_t) * ((size_t)256 * ntiles + 256)));
     uint32_t* hist = c->sort_hist.as<uint32_t>();
@@ -225,7 +248,10 @@ int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint3
         const uint32_t mask = (1u << width) - 1u;  // key bits >= `bits` never take part
         {
             ProfScope ps(c, "radix_hist");
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, n_dev, shift, mask, hist, ntiles);
+            if (n_kept && pass == 0)
+                hipLaunchKernelGGL(radix_hist_kernel<true>, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, n_dev, shift, mask, hist, ntiles);
+            else
+                hipLaunchKernelGGL(radix_hist_kernel<false>, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, n, n_dev, shift, mask, hist, ntiles);
         }
         {
             ProfScope ps(c, "radix_rowscan");
@@ -233,9 +259,14 @@ int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint3
         }
         {
             ProfScope ps(c, "radix_scatter");
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, n_dev,
-                               shift, mask, hist, rowsum, ntiles);
+            if (n_kept && pass == 0)
+                hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, n_dev,
+                                   shift, mask, hist, rowsum, ntiles, n_kept);
+            else
+                hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(ntiles), dim3(kSortBlock), 0, c->stream, ki, vi, ko, vo, n, n_dev,
+                                   shift, mask, hist, rowsum, ntiles, (unsigned long long*)nullptr);
         }
+        if (n_kept && pass == 0) n_dev = n_kept;  // the later passes sort what the first one kept
         GSX_HIP(c, hipGetLastError());
         std::swap(ki, ko);
         std::swap(vi, vo);

@@ -434,6 +434,15 @@ class Context:
         check(self._lib.gsx_debug_sort_pairs(self.h, k.ctypes.data, v.ctypes.data, len(k), bits), self.h)
         return k, v
 
+    def sort_pairs_drop(self, keys, values, bits=16):
+        """The rasterizer's level-1 sort: pairs with key 0xffffffff are left out by the first pass; returns the kept pairs, sorted
+        (stable) by key bits [0, bits) (test hook, gsx_debug_sort_pairs_drop)."""
+        k = np.ascontiguousarray(keys, dtype=np.uint32).copy()
+        v = np.ascontiguousarray(values, dtype=np.uint32).copy()
+        kept = C.c_int64()
+        check(self._lib.gsx_debug_sort_pairs_drop(self.h, k.ctypes.data, v.ctypes.data, len(k), bits, C.byref(kept)), self.h)
+        return k[:kept.value], v[:kept.value]
+
     def synchronize(self):
         check(self._lib.gsx_synchronize(self.h), self.h)
         self._keep_alive.clear()

@@ -125,7 +125,14 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               1e-5 on every pixel), so a dense scene sorts a few times the (tile, splat) pairs the
  *                               blend consumes instead of all of them (3 M splats @1080p: 23.3 M pairs -> 7.2 M with 2
  *                               phases, 2.2 M consumed).  What is skipped could not have moved a channel by 1e-5
- *   "render_phase_ratio" (default 4)  phase p ends after n / ratio^(K-1-p) splats of the depth order (2..64)
+ *   "render_phase_ratio" (default 6)  phase p ends after nvis / ratio^(K-1-p) splats of the depth order (2..64), nvis = the
+ *                               splats the level-1 sort keeps ("render_compact")
+ *   "render_compact" (default 1) rasterizer: the splats without a tile rectangle in the view (behind the camera, off the frame,
+ *                               between the pixel centres, dropped by the JS sort's quirk) get a key that the FIRST pass of
+ *                               the level-1 radix sort leaves out - a stable LSD pass is an order-preserving partition
+ *                               anyway - so the second pass, the bin kernels and their scans see only the others; the
+ *                               depth phases are cut on the device from their count.  0 = every splat is sorted (the
+ *                               phases are then cut from n: the best ratio was 4)
  *   "render_frames" (default 4) gsx_render_views: frames in flight, each on a HIP stream of its own (1..6; 935 / 1252 /
  *                               1359 / 1396 / 1296 / 1349 views/s with 1..6 at 3 M splats @1080p SH 3: four streams for the
  *                               four hardware queues)
@@ -415,6 +422,9 @@ int gsx_ply_write(const gsx_ply* ply, const char* path, const int32_t* labels, i
  * which restates the stable counting sort of gs.js:443-457.  Host arrays, sorted in place.
  * ------------------------------------------------------------------------------------------- */
 int gsx_debug_sort_pairs(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits);
+/* the rasterizer's level-1 sort (csrc/sort.hip: radix_sort_pairs_drop): pairs whose key is 0xffffffff are left out by the first
+ * pass; the others come back sorted (stable) in the first *kept_out slots, the slots behind them hold unspecified values */
+int gsx_debug_sort_pairs_drop(gsx_ctx* ctx, uint32_t* keys, uint32_t* values, int64_t n, int32_t bits, int64_t* kept_out);
 /* test hook, host only (no context, no GPU): the packed form of one map exactly as gsx_vote_view stages it in
  * pinned memory - u8 bins in strips of 16 pixel columns (tiled != 0; row-major otherwise) followed, at *coarse_off
  * (-1: none), by the 4x4-coarsened level.  out == NULL only reports *bytes.  *bad = 1 if a label was out of range. */

@@ -287,6 +287,47 @@ def test_bins_of_2x2_tiles_give_the_frames_of_per_tile_lists(gsx):
             assert np.abs(out[1][0][1] - want).max() <= TOL
 
 
+def test_level_one_sort_without_the_splats_no_tile_sees(gsx):
+    """Option render_compact (default on): bucket_kernel gives the splats without a tile rectangle in the view (behind the
+    camera, off the frame, between the pixel centres, dropped by the JS quirk) the key the level-1 sort leaves out, and the
+    depth phases are cut on the device from the count of the others.  With one phase there is nothing to cut: the frame is
+    bit for bit the one of the full sort.  With more phases the cut falls elsewhere - any cut is valid, what a phase skips is
+    bounded by 1e-5 - so the frames agree to that, and with the oracle to 1e-4.  Cameras inside the cloud (half the splats
+    behind them), far away (most splats smaller than a pixel) and a view that sees nothing at all."""
+    n, W, H = 80_000, 640, 360
+    seed = scene.BASE_SEED + 77
+    xyz = scene.make_positions(n, seed)
+    a = scene.make_splat_attributes(n, seed, sh_degree=1)
+    a["opacity"] += np.float32(1.0)
+    cams = scene.make_cameras(4, W, H, convention="c2w") + scene.make_cameras(3, W, H, radius=1.5, convention="c2w")[:2] \
+        + scene.make_cameras(3, W, H, radius=60.0, convention="c2w")[:1]
+    away = dict(scene.make_cameras(3, W, H, convention="c2w")[0])
+    away["position"] = [float(3.0 * v) for v in away["position"]]
+    away["rotation"] = [[-float(v) if j != 1 else float(v) for j, v in enumerate(row)] for row in away["rotation"]]   # looks away from the cloud
+    cams.append(away)
+    frames = {}
+    with gsx.Context(0) as c:
+        c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+        for phases in (1, 2, 3):
+            c.set_option("render_phases", phases)
+            for compact in (0, 1):
+                c.set_option("render_compact", compact)
+                frames[(phases, compact)] = (c.render_views(cams, W, H), c.render_num_pairs())
+                one = c.render_view(cams[1], W, H)
+                assert np.array_equal(one, frames[(phases, compact)][0][1])
+    for k in range(len(cams)):
+        assert np.array_equal(frames[(1, 0)][0][k], frames[(1, 1)][0][k]), k
+    assert frames[(1, 0)][1] == frames[(1, 1)][1]
+    for phases in (2, 3):
+        for compact in (0, 1):
+            assert np.abs(frames[(phases, compact)][0] - frames[(1, 0)][0]).max() <= 3e-5, (phases, compact)
+    assert float(frames[(2, 1)][0][-1].max()) == 0.0          # the view that looks away
+    assert float(frames[(2, 1)][0][0][..., 3].max()) > 0.9
+    for k in (0, 4, 6):
+        want = oracle.render_scene(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cams[k], W, H)
+        assert np.abs(frames[(2, 1)][0][k] - want).max() <= TOL, k
+
+
 def test_export_splat_file(ctx, g, tmp_path):
     ctx.upload_splats(g["xyz"], g["scale"], g["rot"], g["opacity"], g["f_dc"], g["labels"])
     path = str(tmp_path / "scene.splat")

@@ -78,6 +78,29 @@ def test_radix_sort_is_stable_and_correct(ctx, n, bits):
     assert np.array_equal(v, vals[order]) and np.array_equal(k, keys[order])
 
 
+@pytest.mark.parametrize("n,bits,frac", [(1, 16, 1.0), (1, 16, 0.0), (64, 8, 0.5), (4096, 16, 0.4), (4097, 16, 0.999), (100_003, 16, 0.4), (1_000_000, 24, 0.05),
+                                         (300_000, 16, 0.0)])
+def test_radix_sort_that_leaves_out_marked_pairs(ctx, n, bits, frac):
+    """The rasterizer's level-1 sort (radix_sort_pairs_drop): the first LSD pass is a stable partition anyway, so the pairs
+    whose key is 0xffffffff (splats without a tile rectangle in the view) are simply not counted and not scattered; the
+    later passes sort what remains.  frac = the share that is marked: none, some, nearly all, all; whole tiles of marked
+    pairs, ragged ends."""
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 1 << bits, size=n, dtype=np.uint64).astype(np.uint32)
+    if n == 4096:
+        keys[:] = keys % 5
+    drop = rng.random(n) < frac
+    if n == 100_003:
+        drop[20_000:45_000] = True             # six whole 4096-key tiles without a single kept pair
+    keys[drop] = 0xFFFFFFFF
+    vals = np.arange(n, dtype=np.uint32)
+    k, v = ctx.sort_pairs_drop(keys, vals, bits)
+    kept = np.nonzero(~drop)[0]
+    order = kept[np.argsort(keys[kept], kind="stable")]
+    assert len(k) == len(kept)
+    assert np.array_equal(v, vals[order]) and np.array_equal(k, keys[order])
+
+
 def test_results_do_not_depend_on_tuning_options(gsx):
     n = 70_001
     pos, cams, segs = scene.make_scene(n, 9, 480, 270, config_id=12, convention="w2c")

@@ -47,12 +47,18 @@ with pkg.Context(0) as c:
             ms = {k: c.profile_get(k)[1] / 8 for k in names}
             c.profile(False)
             print(f"render_bin32={b}: kernel ms per view " + " ".join(f"{k}={v:.4f}" for k, v in ms.items()) + f"  sum {sum(ms.values()):.4f}", flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "compact":  # the phase cut once the level-1 sort holds only the splats a tile sees (render_compact)
+        sweep = ({"render_compact": 0}, {}, {"render_phase_ratio": 3}, {"render_phase_ratio": 2}, {"render_phase_ratio": 5},
+                 {"render_phases": 3, "render_phase_ratio": 3}, {"render_phases": 3, "render_phase_ratio": 2}) * 2 + ({"render_compact": 0}, {})
+        if "ratio" in sys.argv[2:]:
+            sweep = ({}, {"render_phase_ratio": 5}, {"render_phase_ratio": 6}, {"render_phase_ratio": 7}, {"render_phase_ratio": 8}, {"render_phase_ratio": 10},
+                     {"render_phases": 3, "render_phase_ratio": 4}) * 2 + ({},)
     if len(sys.argv) > 1 and sys.argv[1] == "cull":    # bounding-box binning against the exact ellipse test, interleaved
         sweep = ({}, {"exact_cull": 1}) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2})
     for opts in sweep:
-        base = {"render_phases": 2, "render_phase_ratio": 4, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2, "render_bin32": 1}
+        base = {"render_phases": 2, "render_phase_ratio": 6, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2, "render_bin32": 1, "render_compact": 1}
         base.update(opts)
         for k, v in base.items():
             c.set_option(k, v)
