@@ -142,7 +142,10 @@ def render_leg(pkg, ctx, args, W, H):
             "views_per_s": round(len(cams) / dt, 2), "gaussian_views_per_s": round(n * len(cams) / dt, 1),
             "views_per_s_note": "gsx_render_views: four frames in flight on four HIP streams of one context (option render_frames)",
             "views_per_s_one_frame_at_a_time": round(len(cams) / dt_one, 2),
-            "tile_splat_pairs_per_view": int(P), "pairs_consumed_per_view": int(Pc), "kernel_ms_per_view": k_ms,
+            "tile_splat_pairs_per_view": int(P), "pairs_consumed_per_view": int(Pc),
+            "pairs_note": "pairs binned, sorted and ranged per view: (32x32-pixel bin, splat) with the mask of the bin's tiles in the value (option render_bin32), "
+                          "splats without a rectangle left out by the level-1 sort (render_compact); consumed = records a tile's wave blended",
+            "kernel_ms_per_view": k_ms,
             "kernel_ms_sum_per_view": round(sum(k_ms.values()), 4),
             "blend_roofline": {"bound": "hbm", "achieved": None if achieved is None else round(achieved, 2), "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 5),
