@@ -15,8 +15,8 @@ src = sys.argv[1]
 dst = os.path.join(src, "summary")
 os.makedirs(dst, exist_ok=True)
 KERNELS = {"vote_fused_labels": "vote_fused_labels_kernel", "seg_pack_fused": "seg_pack_fused_kernel", "blend2": "blend2_kernel", "blend4": "blend4_kernel",
-           "radix_scatter": "radix_scatter_kernel", "radix_hist": "radix_hist_kernel", "pre": "pre_kernel", "bin_count": "bin_kernel<false>",
-           "bin_emit": "bin_kernel<true>", "ranges": "ranges_kernel", "bucket": "bucket_kernel", "unpermute": "unpermute_labels_kernel",
+           "radix_scatter": "radix_scatter_kernel", "radix_hist": "radix_hist_kernel", "pre": "pre_kernel", "bin_count": "bin_kernel<false",
+           "bin_emit": "bin_kernel<true", "ranges": "ranges_kernel", "bucket": "bucket_kernel", "unpermute": "unpermute_labels_kernel",
            "seg_expand": "seg_expand_kernel", "labels_narrow": "labels_narrow_kernel",
            "vote_early_planes": "vote_fused_planes_kernel", "vote_fused_final": "vote_fused_final_kernel",
            "vote_early_record": "vote_record_kernel", "vote_fused_replay": "vote_fused_replay_kernel", "pre_multi": "pre_multi_kernel"}
