@@ -26,8 +26,12 @@ namespace gsx {
 
 static constexpr int kSortBlock = 256;
 static constexpr int kSortWaves = kSortBlock / 64;
-static constexpr int kSortItems = 16;                          // keys per thread
-static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per workgroup (8192 measured 18 % slower)
+#ifndef GSX_SORT_ITEMS
+#define GSX_SORT_ITEMS 16
+#endif
+static constexpr int kSortItems = GSX_SORT_ITEMS;              // keys per thread
+static constexpr int kSortTile = kSortBlock * kSortItems;      // 4096 keys per workgroup (8192 measured 18 % slower; round 3, rasterizer with four
+                                                               // frames in flight, variant libraries: 2048 keys -1.5 %, 1024 keys -6 %: profiles/r03/sort_items_ab.txt)
 static constexpr int kWaveChunk = 64 * kSortItems;             // 1024 consecutive keys per wave
 static constexpr uint32_t kSortDropKey = 0xffffffffu;          // radix_sort_pairs_drop: an element with this key is left out
 

@@ -53,6 +53,8 @@ with pkg.Context(0) as c:
         if "ratio" in sys.argv[2:]:
             sweep = ({}, {"render_phase_ratio": 5}, {"render_phase_ratio": 6}, {"render_phase_ratio": 7}, {"render_phase_ratio": 8}, {"render_phase_ratio": 10},
                      {"render_phases": 3, "render_phase_ratio": 4}) * 2 + ({},)
+    if len(sys.argv) > 1 and sys.argv[1] == "one":     # the defaults, three times (one pass per variant library: GSX_LIBRARY)
+        sweep = ({},) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "cull":    # bounding-box binning against the exact ellipse test, interleaved
         sweep = ({}, {"exact_cull": 1}) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
