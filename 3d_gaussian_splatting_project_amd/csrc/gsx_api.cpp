@@ -143,7 +143,7 @@ void gsx_destroy(gsx_ctx* ctx) {
     for (gsx::DevBuf* b : {&c->x, &c->y, &c->z, &c->perm, &c->sort_hist, &c->d_views, &c->d_cull, &c->d_cull_tally, &c->segpool, &c->errflag,
                            &c->cnt, &c->fv, &c->bcnt, &c->bcodes, &c->keys, &c->labels, &c->cand, &c->codes, &c->r_order, &c->r_buffer, &c->r_tex, &c->r_sh, &c->r_fdc, &c->r_shc, &c->r_image,
                            &c->r_ranges, &c->r_small, &c->r_scan, &c->r_depth, &c->r_bucket, &c->r_rect, &c->r_count,
-                           &c->r_offset, &c->r_rec, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_sat, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3})
+                           &c->r_offset, &c->r_rec, &c->r_keys0, &c->r_keys1, &c->r_vals0, &c->r_vals1, &c->r_tile_order, &c->r_sat, &c->r_d0, &c->r_d1, &c->r_d2, &c->r_d3, &c->r_rects})
         b->release();
     gsx::render_release_twin(c);
     gsx::vote_release_host(c);

@@ -289,6 +289,7 @@ struct Ctx {
     size_t r_pair_cap = 0;               // capacity (pairs) of r_keys*/r_vals*: grown when a phase overflows it, the frame is redone
     unsigned long long r_consumed = 0;   // pairs the blend kernel actually staged (early-out leaves the rest unread)
     DevBuf r_d0, r_d1, r_d2, r_d3;       // level-1 sort ping-pong (bucket, splat)
+    DevBuf r_rects;                      // the tile rectangles of a phase's splats in the phase's order (bin COUNT -> EMIT)
 
     // profiling
     bool prof_on = false;

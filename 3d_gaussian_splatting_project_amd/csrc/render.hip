@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kRB) void bin_kernel(const unsigned long long* __re
                                                    const uint8_t* __restrict__ sat, uint32_t* __restrict__ count_out,
                                                    const uint32_t* __restrict__ offset, uint32_t* __restrict__ keys,
                                                    uint32_t* __restrict__ vals, const unsigned long long* __restrict__ total_dev,
-                                                   unsigned long long cap) {
+                                                   unsigned long long cap, uint32_t* __restrict__ rect_seq) {
     if (EMIT && *total_dev > cap) return;  // the phase does not fit the pair buffers: the host redoes the frame with larger ones
     // the phase's splats: [nvis / div0, nvis / div1) of the depth order, nvis = the splats the level-1 sort kept (on the device:
     // the host never waits for it; the launch covers m_cap >= the phase's length, and COUNT writes every slot of it)
@@ -702,7 +702,10 @@ __global__ __launch_bounds__(kRB) void bin_kernel(const unsigned long long* __re
     const bool live = j < j1;
     const bool slot = rel < m_cap;
     const uint32_t i = live ? by_depth[j] : 0u;
-    const uint32_t rect = live ? tile_rect[i] : kEmptyRect;
+    // COUNT gathers the splat's rectangle (a 4-byte read that costs a whole line) and leaves it in the phase's own order for
+    // EMIT (count_out / offset and rect_seq are per-phase arrays of m_cap slots)
+    const uint32_t rect = live ? (EMIT ? rect_seq[rel] : tile_rect[i]) : kEmptyRect;
+    if (!EMIT && slot) rect_seq[rel] = rect;
     const uint32_t tx0 = rect & 255u, tx1 = (rect >> 8) & 255u, ty0 = (rect >> 16) & 255u, ty1 = rect >> 24;
     constexpr uint32_t kSh = BIN32 ? 1u : 0u;  // candidate = bin: the rectangle in bin units
     const uint32_t w = tx1 >= tx0 ? (tx1 >> kSh) - (tx0 >> kSh) + 1u : 0u;
@@ -1056,6 +1059,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     GSX_HIP(c, c->r_d1.ensure(n4));
     GSX_HIP(c, c->r_d2.ensure(n4));
     GSX_HIP(c, c->r_d3.ensure(n4));
+    GSX_HIP(c, c->r_rects.ensure(n4));
     // depth phases: boundaries nvis / r^(K-1), nvis / r^(K-2), .., nvis / r, nvis of the depth order, nvis = the splats the
     // level-1 sort keeps (on the device); the host sizes a phase's launches for n instead
     const int K = std::max(1, std::min(c->opt_render_phases, kMaxPhases));
@@ -1114,7 +1118,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                     hipLaunchKernelGGL(count_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
                                        nvis_dev, divs[p], divs[p + 1], m, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, c->r_count.as<uint32_t>(), (const uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull);
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (const unsigned long long*)nullptr, 0ull, c->r_rects.as<uint32_t>());
                 }
                 GSX_HIP(c, hipGetLastError());
                 rc = exclusive_scan_u32(c, c->r_count.as<uint32_t>(), c->r_offset.as<uint32_t>(), m, pairs_dev + p);
@@ -1124,7 +1128,7 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                     hipLaunchKernelGGL(emit_k, dim3(grid_for(m)), dim3(kRB), 0, c->stream,
                                        nvis_dev, divs[p], divs[p + 1], m, by_depth, c->r_rect.as<uint32_t>(), c->r_rec.as<float4>(), (float)H, lists_x,
                                        c->opt_exact_cull, sat, (uint32_t*)nullptr, c->r_offset.as<uint32_t>(),
-                                       c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap);
+                                       c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap, c->r_rects.as<uint32_t>());
                 }
                 GSX_HIP(c, hipGetLastError());
                 rc = radix_sort_pairs_dev(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
@@ -1231,7 +1235,7 @@ void render_release_twin(Ctx* c) {
         (void)hipStreamSynchronize(t->stream);
         for (DevBuf* b : {&t->r_tex, &t->r_shc, &t->r_image, &t->r_ranges, &t->r_small, &t->r_scan, &t->r_depth, &t->r_bucket, &t->r_rect,
                           &t->r_count, &t->r_offset, &t->r_rec, &t->r_keys0, &t->r_keys1, &t->r_vals0, &t->r_vals1,
-                          &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->sort_hist, &t->r_pre})
+                          &t->r_tile_order, &t->r_sat, &t->r_d0, &t->r_d1, &t->r_d2, &t->r_d3, &t->r_rects, &t->sort_hist, &t->r_pre})
             b->release();
         for (Ctx::PreSet& ps : t->r_sets)
             for (DevBuf* b : {&ps.depth, &ps.rect, &ps.rec, &ps.pre}) b->release();
