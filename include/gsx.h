@@ -154,7 +154,8 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               is wave-cooperative (no lane walks a rectangle on its own), yet on the 3 M-splat
  *                               scene the test still costs more (+0.18 ms) than the 23 % fewer pairs save (-0.07)
  *   "tile_lpt"     (default 0)  rasterizer: blend the tiles with the longest splat lists first (measured:
- *                               blend -3 %, paid back by the extra ordering launches)
+ *                               blend -3 %, paid back by the extra ordering launches; per-tile lists only: ignored
+ *                               while "render_bin32" is in effect)
  *   "seg_tiled"    (default 1)  keep the u8 seg maps as strips of 16 pixel columns (16x8 pixels per 128-B line;
  *                               applies to the views staged after the call)
  *   "batched_counts" (default 1) more than 255 views on one GPU: one fast u8-histogram launch per batch of <= 255 views
