@@ -203,8 +203,9 @@ __global__ __launch_bounds__(kBlend2Threads) void blend2_kernel(const int2* __re
     if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 acc{};
     if (!first) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 p0 = in0 ? image[(size_t)py0 * W + px] : z, p1 = in1 ? image[(size_t)py1 * W + px] : z;
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+        if (in0) p0 = image[(size_t)py0 * W + px];
+        if (in1) p1 = image[(size_t)py1 * W + px];
         acc.r.x = p0.x, acc.g.x = p0.y, acc.b.x = p0.z, acc.a.x = p0.w;
         acc.r.y = p1.x, acc.g.y = p1.y, acc.b.y = p1.z, acc.a.y = p1.w;
     }
@@ -321,9 +322,12 @@ __global__ __launch_bounds__(kBlend4Threads) void blend4_kernel(const int2* __re
     if (tile_has_nothing_to_do(range, sat, tile, tx, ty, first, last, dropped, pre, n)) return;
     Accum2 accA{}, accB{};
     if (!first) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 p0 = in[0] ? image[(size_t)row * W + px] : z, p1 = in[1] ? image[(size_t)(row + 4) * W + px] : z;
-        const float4 p2 = in[2] ? image[(size_t)(row + 8) * W + px] : z, p3 = in[3] ? image[(size_t)(row + 12) * W + px] : z;
+        // (`in ? image[..] : z` made hipcc keep z in scratch and load through a selected address: 32 bytes of scratch per lane)
+        float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+        if (in[0]) p0 = image[(size_t)row * W + px];
+        if (in[1]) p1 = image[(size_t)(row + 4) * W + px];
+        if (in[2]) p2 = image[(size_t)(row + 8) * W + px];
+        if (in[3]) p3 = image[(size_t)(row + 12) * W + px];
         accA.r.x = p0.x, accA.g.x = p0.y, accA.b.x = p0.z, accA.a.x = p0.w;
         accA.r.y = p1.x, accA.g.y = p1.y, accA.b.y = p1.z, accA.a.y = p1.w;
         accB.r.x = p2.x, accB.g.x = p2.y, accB.b.x = p2.z, accB.a.x = p2.w;
