@@ -183,6 +183,7 @@ int gsx_set_option(gsx_ctx* ctx, const char* name, int64_t value) {
     else if (k == "render_multi_pre") c->opt_render_multi_pre = value != 0;
     else if (k == "render_bin32") c->opt_render_bin32 = value != 0;
     else if (k == "render_compact") c->opt_render_compact = value != 0;
+    else if (k == "render_wide_sort") c->opt_render_wide_sort = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
     else if (k == "render_share_stream") {
         if ((value != 0) != (c->opt_render_share_stream != 0)) gsx::render_release_twin(c);  // the extra frames' streams are made anew
         c->opt_render_share_stream = value != 0;

@@ -281,6 +281,9 @@ struct Ctx {
     int opt_render_bin32 = 1;            // bin, sort and range the splats by 32x32-pixel BINS (2x2 tiles); a pair carries the mask of the bin's tiles
                                          // the splat's rectangle covers (one-wave blend kernel, no exact_cull, < 2^28 splats; else 16x16)
     int opt_render_compact = 1;          // the level-1 sort leaves out the splats without a rectangle in the view (its first pass is the partition)
+    int opt_render_wide_sort = 1;        // the pair sorts in ONE pass when the list index fits 11 bits (sort.hip: radix_sort_values_wide; the ranges come with it):
+                                         // 0 never, 1 for a frame on its own (gsx_render_view), 2 also with several frames in flight
+    bool r_in_flight = false;            // this context renders one of several frames in flight (set by render_views for the call)
     int r_bin32 = 0;                     // the frame being rendered uses bins (set by render_view, read by launch_blend)
     unsigned long long r_P = 0;          // (tile, splat) pairs of the last view (all phases)
     static constexpr int kMaxFrames = 6;
@@ -349,6 +352,8 @@ int radix_sort_pairs_dev(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint3
                          const unsigned long long* n_dev, int bits, int* result_in);
 int radix_sort_pairs_drop(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint32_t* v1, long long n,
                           const unsigned long long* n_dev, int bits, int* result_in, unsigned long long* n_kept);  // elements with key 0xffffffff are left out
+int radix_sort_values_wide(Ctx* c, const uint32_t* k0, const uint32_t* v0, uint32_t* v1, long long n, const unsigned long long* n_dev,
+                           int bits, int2* ranges, int nranges);  // one pass over <= 11 key bits; ranges[d] = slots of key d
 int spatial_sort_positions(Ctx* c);
 int vote_culled(Ctx* c, int64_t* out, bool reset);
 int second_stream(Ctx* c);

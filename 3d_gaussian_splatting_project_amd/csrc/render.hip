@@ -1073,6 +1073,9 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
     }
     int tile_bits = 1;
     while ((1 << tile_bits) < nlists) ++tile_bits;
+    // the pair sorts in one pass (2040 bins at 1080p; 4K: 8160, two passes) - for a frame on its own: 6 % less kernel time; with
+    // several frames in flight its scattered stores cost the other streams more than the saved launches give (option value 2: always)
+    const bool wide = tile_bits <= 11 && (c->opt_render_wide_sort == 2 || (c->opt_render_wide_sort == 1 && !c->r_in_flight));
     if (c->r_pair_cap == 0) c->r_pair_cap = std::max<size_t>((size_t)1 << 20, 2 * (size_t)n);
 
     for (int attempt = 0;; ++attempt) {
@@ -1131,12 +1134,18 @@ int render_view(Ctx* c, const gsx_camera* cam, int W, int H, float* rgba_out) {
                                        c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap, c->r_rects.as<uint32_t>());
                 }
                 GSX_HIP(c, hipGetLastError());
-                rc = radix_sort_pairs_dev(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
-                                          c->r_vals1.as<uint32_t>(), (long long)cap, pairs_dev + p, tile_bits, &where);
+                if (wide) {  // one pass over the whole key; the digits' bases are the lists' ranges (sort.hip)
+                    rc = radix_sort_values_wide(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_vals1.as<uint32_t>(),
+                                                (long long)cap, pairs_dev + p, tile_bits, c->r_ranges.as<int2>(), nlists);
+                    where = 1;
+                } else {
+                    rc = radix_sort_pairs_dev(c, c->r_keys0.as<uint32_t>(), c->r_vals0.as<uint32_t>(), c->r_keys1.as<uint32_t>(),
+                                              c->r_vals1.as<uint32_t>(), (long long)cap, pairs_dev + p, tile_bits, &where);
+                }
                 if (rc) return rc;
             }
-            GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)nlists, c->stream));
-            if (m > 0) {
+            if (!(wide && m > 0)) GSX_HIP(c, hipMemsetAsync(c->r_ranges.p, 0, sizeof(int2) * (size_t)nlists, c->stream));
+            if (m > 0 && !wide) {
                 ProfScope ps(c, "render_ranges");
                 hipLaunchKernelGGL(ranges_kernel, dim3(grid_for((long long)cap)), dim3(kRB), 0, c->stream,
                                    where ? c->r_keys1.as<uint32_t>() : c->r_keys0.as<uint32_t>(), pairs_dev + p, (unsigned long long)cap,
@@ -1218,6 +1227,7 @@ static int twin_sync_scene(Ctx* c, int k) {
     t->opt_exact_cull = c->opt_exact_cull;
     t->opt_render_bin32 = c->opt_render_bin32;
     t->opt_render_compact = c->opt_render_compact;
+    t->opt_render_wide_sort = c->opt_render_wide_sort;
     t->opt_blend_pk2 = c->opt_blend_pk2;
     t->opt_tile_lpt = c->opt_tile_lpt;
     if (t->r_pair_cap < c->r_pair_cap) t->r_pair_cap = c->r_pair_cap;
@@ -1327,6 +1337,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         return GSX_OK;
     };
     auto frames_of = [&](Ctx* t, int f) {
+        t->r_in_flight = true;  // (other frames run next to this context's: render_view picks the forms that share the GPU best)
         int g = 0;
         for (int k = f; k < n && rcs[f] == GSX_OK; k += F, ++g) {
             if (multi) {
@@ -1351,6 +1362,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
             done[f].store(g + 1, std::memory_order_release);
         }
         t->r_pre_ext = -1;
+        t->r_in_flight = false;
         if (rcs[f] != GSX_OK) failed.store(true);  // nobody waits for a pass or a frame that will not come
     };
     if (multi && (rc = issue_pre(0))) return rc;
@@ -1377,6 +1389,7 @@ int render_views(Ctx* c, int n, const gsx_camera* cams, int W, int H, float* con
         throw;
     }
     for (int f = 0; f < started; ++f) others[f].join();
+    for (int f = 0; f < F; ++f) ctxs[f]->r_in_flight = false;
     rc = rcs[0];
     for (int f = 1; f < F && rc == GSX_OK; ++f)
         if (rcs[f] != GSX_OK) {

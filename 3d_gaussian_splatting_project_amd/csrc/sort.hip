@@ -282,6 +282,158 @@ int radix_sort_pairs_drop(Ctx* c, uint32_t* k0, uint32_t* v0, uint32_t* k1, uint
 }
 
 // ---------------------------------------------------------------------------------------------------
+// ONE pass over up to 11 key bits: the rasterizer's pair sort by 32x32-pixel bin (2040 bins at 1080p).
+// Two 8-bit-machinery passes (6 + 5 bits) cost two histograms, two row scans, two scatters with a reorder through LDS each, and
+// the ranges of equal keys then need a kernel of their own.  Here: a 2048-counter LDS histogram per 4096-key tile, the same row
+// scan (one workgroup per digit), and a scatter that ranks with 11 ballots per round and stores the VALUES straight to their
+// final slots (a tile holds about two pairs per bin: there are no runs worth staging) - and since the digit is the whole key,
+// a digit's global base and total ARE the range of its bin: workgroup 0 writes them out.  The keys are not written at all
+// (nothing reads them behind the sort).  Stable by construction: tile, wave (1024 consecutive keys each), round, lane.
+// ---------------------------------------------------------------------------------------------------
+static constexpr int kWideLog = 11;
+static constexpr int kWideDigits = 1 << kWideLog;
+static constexpr int kWidePer = kWideDigits / kSortBlock;  // digits per thread in the per-digit steps
+
+__global__ __launch_bounds__(kSortBlock) void wide_hist_kernel(const uint32_t* __restrict__ keys, long long n,
+                                                                const unsigned long long* __restrict__ n_dev, uint32_t mask,
+                                                                uint32_t* __restrict__ hist, int ntiles) {
+    __shared__ uint32_t h[kWideDigits];
+    n = actual_count(n, n_dev);
+    if ((long long)blockIdx.x * kSortTile >= n) return;
+#pragma unroll
+    for (int k = 0; k < kWidePer; ++k) h[threadIdx.x + k * kSortBlock] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * kSortTile;
+#pragma unroll 4
+    for (int k = 0; k < kSortItems; ++k) {
+        const long long i = base + (long long)k * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[keys[i] & mask], 1u);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWidePer; ++k) {
+        const int d = threadIdx.x + k * kSortBlock;
+        hist[(long long)d * ntiles + blockIdx.x] = h[d];
+    }
+}
+
+__global__ __launch_bounds__(kSortBlock) void wide_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   uint32_t* __restrict__ vals_out, long long n,
+                                                                   const unsigned long long* __restrict__ n_dev, uint32_t mask,
+                                                                   const uint32_t* __restrict__ hist,
+                                                                   const uint32_t* __restrict__ rowsum, int ntiles,
+                                                                   int2* __restrict__ ranges, int nranges) {
+    __shared__ uint32_t gbase[kWideDigits];               // global slot of this tile's first element of each digit
+    __shared__ uint32_t wcount[kSortWaves][kWideDigits];  // per-wave digit counters, then the waves' exclusive bases inside the tile's run
+    __shared__ uint32_t wsum[kSortWaves];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    n = actual_count(n, n_dev);
+    const bool active = (long long)blockIdx.x * kSortTile < n;  // workgroup-uniform
+    if (!active && blockIdx.x != 0) return;                      // (workgroup 0 writes the ranges even of an empty sort)
+    {
+        // digit bases: thread t owns the digits [8 t, 8 t + 8): exclusive scan of rowsum over all digits
+        uint32_t rs[kWidePer];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < kWidePer; ++k) {
+            rs[k] = rowsum[threadIdx.x * kWidePer + k];
+            sum += rs[k];
+        }
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+        for (int k = 0; k < kWidePer; ++k) {
+            const int d = threadIdx.x * kWidePer + k;
+            if (blockIdx.x == 0 && d < nranges) ranges[d] = make_int2((int)run, (int)(run + rs[k]));
+            gbase[d] = run + (active ? hist[(long long)d * ntiles + blockIdx.x] : 0u);
+            run += rs[k];
+#pragma unroll
+            for (int w = 0; w < kSortWaves; ++w) wcount[w][d] = 0;
+        }
+    }
+    if (!active) return;
+    __syncthreads();
+    const long long wbase_idx = (long long)blockIdx.x * kSortTile + (long long)wave * kWaveChunk;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t dig[kSortItems];
+    uint32_t val[kSortItems];
+    uint32_t rank[kSortItems];
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const long long i = wbase_idx + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t dg = valid ? keys_in[i] & mask : 0u;
+        val[r] = valid ? vals_in[i] : 0u;
+        dig[r] = dg;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < kWideLog; ++b) {
+            const unsigned long long m = __ballot((dg >> b) & 1u);
+            peers &= ((dg >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = wcount[wave][dg];
+        rank[r] = before + (uint32_t)__popcll(peers & lt);
+        // the wave runs in lockstep: every lane has read `before` before the leader's store issues
+        if (valid && (peers & lt) == 0ull) wcount[wave][dg] = before + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kWidePer; ++k) {  // the waves' exclusive bases inside the tile's run of digit d
+        const int d = threadIdx.x + k * kSortBlock;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t c = wcount[w][d];
+            wcount[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r) {
+        const long long i = wbase_idx + r * 64 + lane;
+        if (i < n) vals_out[gbase[dig[r]] + wcount[wave][dig[r]] + rank[r]] = val[r];
+    }
+}
+
+// Sorts the VALUES of n pairs (count on the device if n_dev) by key bits [0, bits), bits <= 11, in one pass: v0 -> v1; the keys
+// are only read.  ranges[d] = [first, last + 1) slot of key d for d < nranges (<= 2048), written whatever the count.
+int radix_sort_values_wide(Ctx* c, const uint32_t* k0, const uint32_t* v0, uint32_t* v1, long long n, const unsigned long long* n_dev,
+                           int bits, int2* ranges, int nranges) {
+    if (n <= 0 || bits < 1 || bits > kWideLog || nranges > kWideDigits || !ranges)
+        return fail(c, GSX_E_INVALID, "radix_sort_values_wide: bad arguments");
+    const int ntiles = (int)((n + kSortTile - 1) / kSortTile);
+    GSX_HIP(c, c->sort_hist.ensure(sizeof(uint32_t) * ((size_t)kWideDigits * ntiles + kWideDigits)));
+    uint32_t* hist = c->sort_hist.as<uint32_t>();
+    uint32_t* rowsum = hist + (size_t)kWideDigits * ntiles;
+    const uint32_t mask = (1u << bits) - 1u;
+    {
+        ProfScope ps(c, "radix_hist");
+        hipLaunchKernelGGL(wide_hist_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, k0, n, n_dev, mask, hist, ntiles);
+    }
+    {
+        ProfScope ps(c, "radix_rowscan");
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kWideDigits), dim3(kSortBlock), 0, c->stream, hist, ntiles, n, n_dev, rowsum);
+    }
+    {
+        ProfScope ps(c, "radix_scatter");
+        hipLaunchKernelGGL(wide_scatter_kernel, dim3(ntiles), dim3(kSortBlock), 0, c->stream, k0, v0, v1, n, n_dev, mask, hist, rowsum,
+                           ntiles, ranges, nranges);
+    }
+    GSX_HIP(c, hipGetLastError());
+    return GSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Morton order of the positions (performance only: results never depend on the order)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float finite_or(float v, float alt) { return (v - v == 0.0f) ? v : alt; }

@@ -146,6 +146,11 @@ int gsx_synchronize(gsx_ctx* ctx);
  *                               it, in list order: 7.45 M -> 2.87 M pairs per view at 3 M splats @1080p, 1610-1650 ->
  *                               1910-1960 views/s, frames bit-identical.  Needs "blend_pk2" = 2, "exact_cull" = 0 and
  *                               fewer than 2^28 splats; otherwise (or with 0) the lists are per 16x16 tile
+ *   "render_wide_sort" (default 1) rasterizer: with at most 2048 lists (32x32-pixel bins up to about 1440p) the pair sort is ONE radix
+ *                               pass over the whole 11-bit key whose digit bases are the lists' ranges (no second pass, no ranges
+ *                               kernel, no keys written): 1 = for a frame on its own (gsx_render_view: 6 % less kernel time), 2 =
+ *                               also with several frames in flight (measured 1 % slower there: its stores are scattered), 0 = never.
+ *                               The same lists, bit-identical frames
  *   "render_share_stream" (default 1)  gsx_render_views: the first extra frame runs on the context's second stream (the
  *                               early vote's) instead of one more stream - a context that has labelled before would
  *                               otherwise hold five streams for four hardware queues (1120 instead of 1340 views/s)

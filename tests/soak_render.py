@@ -29,7 +29,7 @@ with gsx.Context(0) as c:
         opts = {"render_phases": int(rng.integers(1, 9)), "render_phase_ratio": int(rng.choice([2, 3, 4, 8])),
                 "exact_cull": int(rng.random() < 0.5), "blend_pk2": int(rng.integers(0, 3)), "tile_lpt": int(rng.random() < 0.2),
                 "render_frames": int(rng.integers(1, 7)), "render_multi_pre": int(rng.random() < 0.8),
-                "render_bin32": int(rng.random() < 0.7), "render_compact": int(rng.random() < 0.7)}
+                "render_bin32": int(rng.random() < 0.7), "render_compact": int(rng.random() < 0.7), "render_wide_sort": int(rng.integers(0, 3))}
         for k, v in opts.items():
             c.set_option(k, v)
         s = scene.BASE_SEED + int(rng.integers(1 << 20))

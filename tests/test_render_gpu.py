@@ -270,6 +270,7 @@ def test_bins_of_2x2_tiles_give_the_frames_of_per_tile_lists(gsx):
             c.set_option("render_phases", phases)
             for b in (0, 1):
                 c.set_option("render_bin32", b)
+                c.set_option("render_wide_sort", (1, 2)[n % 2] if b else 0)   # the one-pass pair sort: for single frames only / always
                 many = c.render_views(cams, W, H)
                 stats = (c.render_num_pairs(), c.render_num_pairs_consumed())
                 single = [c.render_view(cam, W, H) for cam in cams[:2]]
@@ -285,6 +286,41 @@ def test_bins_of_2x2_tiles_give_the_frames_of_per_tile_lists(gsx):
         if deg == 0 and n <= 60_000:
             want = oracle.render_scene(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"], cams[1], W, H)
             assert np.abs(out[1][0][1] - want).max() <= TOL
+
+
+def test_pair_sort_in_one_pass_gives_the_same_lists(gsx):
+    """Option render_wide_sort: with at most 2048 lists (32x32-pixel bins up to about 1440p) the (bin, splat) pairs are sorted in ONE
+    radix pass over the whole 11-bit key (sort.hip: radix_sort_values_wide) whose digit bases are the lists' ranges - no second
+    pass, no ranges kernel, no keys written.  The lists are the same, so the frames are bit for bit those of the two-pass sort:
+    a frame on its own (value 1, the default, and 2), several frames in flight (2), empty phases and views that see nothing,
+    a frame of a single bin, one to three depth phases; 4K frames (8160 bins) take the two-pass sort whatever the option."""
+    for n, W, H, phases in ((30_000, 640, 360, 2), (120_000, 1920, 1080, 2), (2_000, 31, 17, 1), (60_000, 1000, 600, 3), (20_000, 3840, 2160, 2)):
+        seed = scene.BASE_SEED + 5 * n
+        xyz = scene.make_positions(n, seed)
+        a = scene.make_splat_attributes(n, seed, sh_degree=1)
+        a["scale"] += np.float32(np.log(2.0))
+        a["opacity"] += np.float32(1.5)
+        cams = scene.make_cameras(5, W, H, convention="c2w")
+        away = dict(cams[0])
+        away["position"] = [float(3.0 * v) for v in away["position"]]
+        away["rotation"] = [[-float(v) if j != 1 else float(v) for j, v in enumerate(row)] for row in away["rotation"]]
+        cams.append(away)
+        out = {}
+        with gsx.Context(0) as c:
+            c.upload_splats(xyz, a["scale"], a["rot"], a["opacity"], a["f_dc"])
+            c.set_option("render_phases", phases)
+            for wide in (0, 1, 2):
+                c.set_option("render_wide_sort", wide)
+                single = [c.render_view(cam, W, H) for cam in cams]
+                pairs = c.render_num_pairs()
+                many = c.render_views(cams, W, H) if W < 3000 else single
+                out[wide] = (single, many, pairs)
+        for wide in (1, 2):
+            for k in range(len(cams)):
+                assert np.array_equal(out[0][0][k], out[wide][0][k]), (n, W, H, wide, k)
+                assert np.array_equal(out[0][0][k], out[wide][1][k]), (n, W, H, wide, k, "in flight")
+            assert out[0][2] == out[wide][2]
+        assert float(out[1][0][-1].max()) == 0.0 and float(out[1][0][0][..., 3].max()) > 0.5
 
 
 def test_level_one_sort_without_the_splats_no_tile_sees(gsx):

@@ -55,12 +55,26 @@ with pkg.Context(0) as c:
                      {"render_phases": 3, "render_phase_ratio": 4}) * 2 + ({},)
     if len(sys.argv) > 1 and sys.argv[1] == "one":     # the defaults, three times (one pass per variant library: GSX_LIBRARY)
         sweep = ({},) * 3
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":    # the pair sorts in one 11-bit pass (ranges included) against two passes + ranges kernel
+        sweep = ({"render_wide_sort": 0}, {"render_wide_sort": 2}, {"render_wide_sort": 1}) * 3
+        for b in (0, 1):
+            c.set_option("render_wide_sort", b)
+            c.render_view(cams[0], W, H, to_host=False)
+            c.profile(True)
+            for cam in cams[:8]:
+                c.render_view(cam, W, H, to_host=False)
+            names = ("render_pre", "render_bucket", "radix_hist", "radix_rowscan", "radix_scatter", "render_bin_count", "scan", "render_bin_emit", "render_ranges", "render_blend")
+            have = set(c.profile_names())
+            ms = {k: (c.profile_get(k)[1] / 8 if k in have else 0.0) for k in names}
+            c.profile(False)
+            print(f"render_wide_sort={b}: kernel ms per view " + " ".join(f"{k}={v:.4f}" for k, v in ms.items()) + f"  sum {sum(ms.values()):.4f}", flush=True)
     if len(sys.argv) > 1 and sys.argv[1] == "cull":    # bounding-box binning against the exact ellipse test, interleaved
         sweep = ({}, {"exact_cull": 1}) * 3
     if len(sys.argv) > 1 and sys.argv[1] == "blend1":  # one pass over both kernels (tools/blend_chunks.sh runs it per variant library)
         sweep = ({"blend_pk2": 1}, {"blend_pk2": 2})
     for opts in sweep:
-        base = {"render_phases": 2, "render_phase_ratio": 6, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2, "render_bin32": 1, "render_compact": 1}
+        base = {"render_phases": 2, "render_phase_ratio": 6, "exact_cull": 0, "tile_lpt": 0, "blend_pk2": 2, "render_bin32": 1, "render_compact": 1, "render_wide_sort": 1}
+        # (render_wide_sort 1: the one-pass pair sort for a frame on its own only, 2: also with frames in flight)
         base.update(opts)
         for k, v in base.items():
             c.set_option(k, v)
