@@ -480,6 +480,32 @@ inline unsigned rows16<int32_t, 1u>(const int32_t* src, size_t pitch, int rows, 
     if (g_avx512) return rows16_i32_avx512(src, pitch, rows, bins, out, opitch);
     return g_avx2 ? rows16_i32_avx2(src, pitch, rows, bins, out, opitch) : rows16_scalar<int32_t, 1u>(src, pitch, rows, bins, out, opitch);
 }
+// uint8 sources (8-bit class images: ADD = 1; already packed bins: ADD = 0): one 16-byte load, compare, add and store per group -
+// SSE2, the x86-64 baseline.  bin = v + ADD >= bins  <=>  v >= bins - ADD (never, if that exceeds 255).  (The scalar form made the
+// hand-over of 200 uint8 1080p maps SLOWER than that of the int32 maps they are a quarter of: 11.0 against 9.0 ms per run.)
+template <unsigned ADD>
+static inline unsigned rows16_u8_sse2(const uint8_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    if (bins < ADD) return rows16_scalar<uint8_t, ADD>(src, pitch, rows, bins, out, opitch);
+    const unsigned lim_u = bins - ADD;
+    const __m128i lim = _mm_set1_epi8((char)(lim_u > 255u ? 255u : lim_u));
+    const __m128i add = _mm_set1_epi8((char)ADD);
+    __m128i acc = _mm_setzero_si128();
+    for (int r = 0; r < rows; ++r) {
+        if ((r & 3) == 0) prefetch_map(src + (size_t)r * pitch + g_prefetch_bytes);  // one line = four groups
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src + (size_t)r * pitch));
+        acc = _mm_or_si128(acc, _mm_cmpeq_epi8(_mm_max_epu8(v, lim), v));  // v >= lim (unsigned)
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(out + (size_t)r * opitch), _mm_add_epi8(v, add));
+    }
+    return lim_u > 255u ? 0u : (unsigned)(_mm_movemask_epi8(acc) != 0);
+}
+template <>
+inline unsigned rows16<uint8_t, 1u>(const uint8_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    return rows16_u8_sse2<1u>(src, pitch, rows, bins, out, opitch);
+}
+template <>
+inline unsigned rows16<uint8_t, 0u>(const uint8_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
+    return rows16_u8_sse2<0u>(src, pitch, rows, bins, out, opitch);
+}
 template <>
 inline unsigned rows16<int64_t, 1u>(const int64_t* src, size_t pitch, int rows, unsigned bins, uint8_t* out, size_t opitch) {
     return g_avx2 ? rows16_i64_avx2(src, pitch, rows, bins, out, opitch) : rows16_scalar<int64_t, 1u>(src, pitch, rows, bins, out, opitch);

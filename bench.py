@@ -474,6 +474,34 @@ def main():
                                             "the 4x4 cells whose pixels differ), expanded to the two-level pool form on the GPU"}
         ctx.vote_finalize(out=labels_buf)
 
+        # 8-bit class images (GSX_SEG_U8_LABELS): what a caller hands over whose segmentation network writes uint8 class maps - a
+        # quarter of the bytes the host pass has to read.  u8 holds 0 .. classes-1 only, so the maps' -1 pixels become class 0 here;
+        # the labels are checked against a run over the SAME maps handed over as int32.
+        if args.classes <= 255 and V <= 255:
+            segs_u8 = [np.where(sg < 0, 0, sg).astype(np.uint8) for sg in host_segs]
+
+            def step_u8(maps):
+                ctx.vote_begin(args.classes, 0, total_views)
+                for v in range(V):
+                    ctx.vote_view(cam_structs[v], maps[v])
+                ctx.vote_finalize(out=labels_buf)
+            step_u8([m8.astype(np.int32) for m8 in segs_u8])
+            want_u8 = labels_buf.copy()
+            for _ in range(2):
+                step_u8(segs_u8)
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(S + 2):
+                step_u8(segs_u8)
+            ctx.synchronize()
+            dt = (time.perf_counter() - t1) / (S + 2)
+            side["u8_class_images"] = {"value": round(n * total_views / dt, 1), "ms_per_step": round(dt * 1e3, 4),
+                                       "map_bytes": int(sum(m8.nbytes for m8 in segs_u8)),
+                                       "labels_equal_int32_run_on_the_same_maps": bool(np.array_equal(labels_buf, want_u8)),
+                                       "note": "the metric's span with uint8 class images handed over instead of int32 maps (-1 pixels set to class 0): "
+                                               "not the headline (SURVEY 8(d) hands over int32), the lever left in the hand-over"}
+            del segs_u8
+
     # ---- CPU baseline: the oracle (C port of the reference loop) on bounded samples of the same workload ----------------
     cpu = None
     if rank == 0 and not multi and args.cpu_sample > 0:

@@ -71,7 +71,7 @@ def test_range_check():
     ok = np.full((9, 21), 149, np.int32)
     assert not labeler.host_pack(ok, 150)[2]
     for bad_value, dtype in ((150, np.int32), (-2, np.int32), (2 ** 31 - 1, np.int32), (-2 ** 31, np.int32), (150, np.int64),
-                             (-2, np.int64), (2 ** 40, np.int64), (2 ** 32 - 1, np.int64), (-2 ** 63, np.int64), (150, np.uint8)):
+                             (-2, np.int64), (2 ** 40, np.int64), (2 ** 32 - 1, np.int64), (-2 ** 63, np.int64), (150, np.uint8), (255, np.uint8)):
         for pos in ((0, 0), (8, 20), (4, 16), (3, 15)):
             m = ok.astype(dtype)
             m[pos] = bad_value
@@ -80,6 +80,15 @@ def test_range_check():
     assert not labeler.host_pack(packed, 150, packed_u8=True)[2]
     packed[5, 5] = 151
     assert labeler.host_pack(packed, 150, packed_u8=True)[2]
+    packed[5, 5] = 255
+    assert labeler.host_pack(packed, 150, packed_u8=True)[2]
+    # 8-bit sources with 255 classes: every byte is a valid label (bin = label + 1 <= 255 < 256 bins) except 255 itself
+    wide = np.arange(9 * 32, dtype=np.int64).reshape(9, 32) % 255
+    assert not labeler.host_pack(wide.astype(np.uint8), 255)[2]
+    out8 = labeler.host_pack(wide.astype(np.uint8), 255)[0]
+    assert np.array_equal(out8, labeler.host_pack(wide.astype(np.int32), 255)[0])
+    wide[7, 3] = 255
+    assert labeler.host_pack(wide.astype(np.uint8), 255)[2]
     # 255 classes: bin 255 is a real class, so no coarse level is built (255 could not mean "mixed")
     out, coff, bad = labeler.host_pack(np.full((8, 16), 254, np.int32), 255)
     assert coff == -1 and not bad and (out[:128] == 255).all()
