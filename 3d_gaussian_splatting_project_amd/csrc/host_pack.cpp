@@ -556,12 +556,21 @@ static void pack_band_tiled(PackJob* j, int part) {
         }
         continues_at = end;
     }
+    // Compact form: nothing reads the strips behind this function (the coarse bytes and the mixed cells' blocks are all that
+    // leaves), so the band's lines need not live in a map-sized scratch whose every line is a fresh miss - they go to a buffer
+    // of this thread that the next band reuses: `strips` lines of 128 bytes, in the first-level cache for good.
+    const bool local = j->stream != nullptr;
+    static thread_local std::vector<uint8_t> lines_tl;
+    if (local && lines_tl.size() < (size_t)strips * 128 + 64) lines_tl.resize((size_t)strips * 128 + 64);
+    uint8_t* const lbase = local ? lines_tl.data() + ((64 - (reinterpret_cast<uintptr_t>(lines_tl.data()) & 63)) & 63) : nullptr;
+    const size_t spitch = local ? (size_t)128 : (size_t)L.strip_bytes;             // from one strip's line to the next strip's
+    uint8_t* const band0 = local ? lbase : dst + (size_t)band * 128;               // the band's line of strip 0
     for (int y = y0; y < y1; ++y) {
         const T* row = seg + (size_t)y * L.w;
-        uint8_t* o = dst + (size_t)y * 16;  // row y of strip 0
-        if (full) bad |= rows16<T, ADD>(row, 16, full, bins, o, (size_t)L.strip_bytes);
+        uint8_t* o = band0 + (size_t)(y - r0) * 16;  // row y of strip 0
+        if (full) bad |= rows16<T, ADD>(row, 16, full, bins, o, spitch);
         if (full < strips) {  // ragged last strip: columns past the map hold bin 0
-            uint8_t* e = o + (size_t)full * L.strip_bytes;
+            uint8_t* e = o + (size_t)full * spitch;
             std::memset(e, 0, 16);
             bad |= narrow_n<T, ADD>(row + (size_t)full * 16, L.w - full * 16, bins, e);
         }
@@ -569,7 +578,7 @@ static void pack_band_tiled(PackJob* j, int part) {
     for (int s = 0; s < strips; ++s) {
         const int x0 = s * 16;
         const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
-        uint8_t* line = dst + (size_t)s * L.strip_bytes + (size_t)band * 128;
+        uint8_t* line = band0 + (size_t)s * spitch;
         const int z0 = y1 > r0 ? y1 : r0;  // this band's rows past the map: defined bytes
         if (z0 < r1) std::memset(line + (size_t)(z0 - band * 8) * 16, 0, (size_t)(r1 - z0) * 16);
         if (L.cstrip_bytes) {
@@ -636,11 +645,11 @@ static void pack_band_tiled(PackJob* j, int part) {
             uint8_t* out = j->stream + (size_t)first * 16;
             first += n[cyl];
             if (!n[cyl]) continue;
-            const uint8_t* rows = dst + (size_t)(band * 8 + cyl * 4) * 16;  // row 4*cyl of the band in strip 0
+            const uint8_t* rows = band0 + (size_t)(cyl * 4) * 16;  // row 4*cyl of the band in strip 0
             for (int cs = 0; cs < ncs; ++cs) {
                 for (unsigned m = masks[cyl][cs]; m; m &= m - 1) {
                     const int cx = cs * 16 + __builtin_ctz(m);
-                    const uint8_t* q = rows + (size_t)(cx >> 2) * L.strip_bytes + (cx & 3) * 4;  // rows 16 bytes apart
+                    const uint8_t* q = rows + (size_t)(cx >> 2) * spitch + (cx & 3) * 4;  // rows 16 bytes apart
                     uint32_t r[4];
                     std::memcpy(&r[0], q, 4), std::memcpy(&r[1], q + 16, 4), std::memcpy(&r[2], q + 32, 4), std::memcpy(&r[3], q + 48, 4);
                     std::memcpy(out, r, 16);
