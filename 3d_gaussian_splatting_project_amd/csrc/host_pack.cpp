@@ -463,11 +463,38 @@ __attribute__((target("avx2"))) static uint32_t coarse_word_avx2(const uint8_t* 
     const __m128i val = _mm_blendv_epi8(_mm_set1_epi8((char)255), first, eq);
     return (uint32_t)_mm_cvtsi128_si32(_mm_shuffle_epi8(val, _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1)));
 }
+// ... for one cell row of a band and its first 4 * n4 strips at once: everything inlined, the constants loaded once, and the four
+// words of four consecutive strips stored as the 16 bytes they are in the coarse level (a coarse strip = 16 cell columns).  lines =
+// the cell row's first row in strip 0, the strips' lines spitch apart; co = the cell row's 16 bytes of coarse strip 0.
+__attribute__((target("avx2"))) static void coarse_row_avx2(const uint8_t* __restrict__ lines, size_t spitch, int n4,
+                                                            uint8_t* __restrict__ co, size_t cstrip_bytes) {
+    const __m128i pick = _mm_setr_epi8(0, 0, 0, 0, 4, 4, 4, 4, 8, 8, 8, 8, 12, 12, 12, 12);
+    const __m128i gather = _mm_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    const __m128i ones = _mm_set1_epi32(-1), mixed = _mm_set1_epi8((char)255);
+    for (int g = 0; g < n4; ++g) {
+        __m128i w[4];
+        for (int k = 0; k < 4; ++k) {
+            const uint8_t* q = lines + (size_t)(4 * g + k) * spitch;
+            const __m128i r0 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q));
+            const __m128i r1 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 16));
+            const __m128i r2 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 32));
+            const __m128i r3 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(q + 48));
+            const __m128i first = _mm_shuffle_epi8(r0, pick);
+            __m128i eq = _mm_and_si128(_mm_and_si128(_mm_cmpeq_epi8(r0, first), _mm_cmpeq_epi8(r1, first)),
+                                       _mm_and_si128(_mm_cmpeq_epi8(r2, first), _mm_cmpeq_epi8(r3, first)));
+            eq = _mm_cmpeq_epi32(eq, ones);
+            w[k] = _mm_shuffle_epi8(_mm_blendv_epi8(mixed, first, eq), gather);  // the strip's word in the low 4 bytes
+        }
+        const __m128i lo = _mm_unpacklo_epi32(w[0], w[1]), hi = _mm_unpacklo_epi32(w[2], w[3]);
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(co + (size_t)g * cstrip_bytes), _mm_unpacklo_epi64(lo, hi));
+    }
+}
 static const bool g_avx2 = __builtin_cpu_supports("avx2");
 static const bool g_avx512 = __builtin_cpu_supports("avx512f") && !std::getenv("GSX_HOST_NO_AVX512");
 #else
 static const bool g_avx2 = false;
 static uint32_t coarse_word_avx2(const uint8_t*) { return 0; }
+static void coarse_row_avx2(const uint8_t*, size_t, int, uint8_t*, size_t) {}
 #endif
 
 template <typename T, unsigned ADD>
@@ -575,7 +602,15 @@ static void pack_band_tiled(PackJob* j, int part) {
             bad |= narrow_n<T, ADD>(row + (size_t)full * 16, L.w - full * 16, bins, e);
         }
     }
-    for (int s = 0; s < strips; ++s) {
+    // a band that lies inside the map: its two cell rows' coarse bytes four strips at a time (coarse_row_avx2); the strips that are
+    // left (and every strip of a ragged band, or without AVX2) take the general loop below
+    int s_fast = 0;
+    if (g_avx2 && L.cstrip_bytes && y1 == r1 && band * 2 + 2 <= L.ch && band * 8 + 8 <= L.h) {
+        s_fast = (full / 4) * 4;
+        for (int cyl = c0; cyl < c1 && s_fast; ++cyl)
+            coarse_row_avx2(band0 + (size_t)cyl * 64, spitch, s_fast / 4, j->coarse + (size_t)(band * 2 + cyl) * 16, (size_t)L.cstrip_bytes);
+    }
+    for (int s = s_fast; s < strips; ++s) {
         const int x0 = s * 16;
         const int cnt = L.w - x0 >= 16 ? 16 : L.w - x0;
         uint8_t* line = band0 + (size_t)s * spitch;
